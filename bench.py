@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- batched SQP-RTI solves/s of the path-tracking OCP on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched
+under torch.distributed.run, one rank per GPU.  A *step* is one SQP-RTI solve of one batch of
+B = 4096 independent OCP instances per GPU (BASELINE.json configs[1]: N = 40, dt = 0.35,
+randomised states / cubic path coefficients, fp64), started from the cold initial guess
+x_k = x0, u_k = 0 (src/AcadosSolver.cpp:78-92) so that every step does identical work.
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Extra keys: `roofline` (dominant kernel vs the fp64 vector peak; HBM view alongside),
+`cpu_baseline` (the CPU oracle on the GPU box's host cores: a restatement, NOT acados), `warm`
+(same measurement for warm-started RTI calls), `multi_gpu` (with/without the RCCL all-gather).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # = 1/2 of the 157.3 TF fp32 vector spec (MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0
+
+
+def flops_per_solve(N, n_ipm):
+    # F(N, n_ipm) = N (1400 + 2200 n_ipm + 16)
+    return N * (1400.0 + 2200.0 * n_ipm + 16.0)
+
+
+def bytes_per_solve(N, warm):
+    cold = 8 * (6 + 6) + 8 * (8 * N + 6) + 16
+    return cold + (8 * (8 * N + 6) if warm else 0)
+
+
+class Hip:
+    """Minimal ctypes view of the HIP runtime for event timing on the solver's stream."""
+
+    def __init__(self):
+        self.l = C.CDLL("libamdhip64.so")
+        self.l.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.l.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        self.l.hipEventSynchronize.argtypes = [C.c_void_p]
+        self.l.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        self.l.hipEventDestroy.argtypes = [C.c_void_p]
+
+    def event(self):
+        e = C.c_void_p()
+        assert self.l.hipEventCreate(C.byref(e)) == 0
+        return e
+
+    def record(self, e, stream):
+        assert self.l.hipEventRecord(e, stream) == 0
+
+    def elapsed_ms(self, a, b):
+        assert self.l.hipEventSynchronize(b) == 0
+        ms = C.c_float()
+        assert self.l.hipEventElapsedTime(C.byref(ms), a, b) == 0
+        return float(ms.value)
+
+
+def cpu_baseline(N, seconds_target=12.0):
+    """Time the CPU oracle (oracle/nmpc_oracle.c, 'port': a restatement, not acados/HPIPM) on a
+    bounded sample of the same workload, one instance per thread on the host cores we may use."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    from mpc_local_planner_amd import capi, scenarios as sc
+    c = capi.default_config(N, 0.35)
+    ocfg = orc.default_config(N, 0.35, ipm_mu0=c.ipm_mu0, ipm_thr0=c.ipm_thr0, ipm_tau=c.ipm_tau,
+                              ipm_tol_mu=c.ipm_tol_mu, ipm_tol_lin=c.ipm_tol_lin,
+                              ipm_max_iter=c.ipm_max_iter)
+    x0, p = sc.config2(64)
+    t = time.perf_counter()
+    orc.rti_batch(ocfg, x0, p)
+    per = (time.perf_counter() - t) / 64
+    cores = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1),
+                       os.cpu_count() or 1, 16))
+    chunk = max(8, int(seconds_target / per / cores / 4))
+    nchunks = cores * 4
+    total = chunk * nchunks
+    x0, p = sc.config2(total)
+    # single core
+    n1 = max(64, int(min(total, 3.0 / per)))
+    t = time.perf_counter()
+    orc.rti_batch(ocfg, x0[:n1], p[:n1])
+    single = n1 / (time.perf_counter() - t)
+
+    def work(i):
+        orc.rti_batch(ocfg, x0[i * chunk:(i + 1) * chunk], p[i * chunk:(i + 1) * chunk])
+    t = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(work, range(nchunks)))
+    multi = total / (time.perf_counter() - t)
+    return {"value": multi, "unit": "solves/s", "cores": cores, "kind": "port",
+            "single_core_value": single,
+            "sample": f"{total} cold SQP-RTI solves (N={N}) of the config-2 distribution, "
+                      f"one instance per thread; CPU restatement (oracle/), not acados/HPIPM"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--horizon", type=int, default=40)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mpc_local_planner_amd import capi, scenarios as sc
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    N, B = args.horizon, args.batch
+    solver = capi.BatchSolver(N=N, dt=0.35, capacity=B, device=local_rank)
+    x0, p = sc.config2(B, start=rank * B)        # this rank's shard of the global batch
+    solver.set_x0(x0)
+    solver.set_params(p)                         # inputs now resident in HBM
+    hip = Hip()
+    stream = solver.stream()
+
+    # control records of all ranks (RCCL all-gather over xGMI), zero-copy view of the handle's buffer
+    class _Arr:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False),
+                                             "version": 2}
+    ctrl_local = torch.as_tensor(_Arr(solver.device_ptr(0), B * 6), device=f"cuda:{local_rank}")
+    ctrl_all = torch.empty(world * B * 6, dtype=torch.float64, device=f"cuda:{local_rank}") if world > 1 else None
+
+    def barrier():
+        solver.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def run(steps, cold, gather, events=None):
+        for s in range(steps):
+            if cold:
+                solver.reset(None, B)
+            if events is not None:
+                hip.record(events[2 * s], stream)
+            solver.solve(B)
+            if events is not None:
+                hip.record(events[2 * s + 1], stream)
+            if gather and world > 1:
+                solver.sync()
+                dist.all_gather_into_tensor(ctrl_all, ctrl_local)
+
+    def timed(steps, cold, gather, with_events=False):
+        events = [hip.event() for _ in range(2 * steps)] if with_events else None
+        barrier()
+        t0 = time.perf_counter()
+        run(steps, cold, gather, events)
+        barrier()
+        dt = time.perf_counter() - t0
+        kms = None
+        if events:
+            kms = float(np.mean([hip.elapsed_ms(events[2 * s], events[2 * s + 1]) for s in range(steps)]))
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, kms
+
+    gather = world > 1
+    run(args.warmup, True, gather)
+    dt_main, kernel_ms = timed(args.steps, True, gather, with_events=True)
+    g = solver.get(B)
+    n_ipm_cold = float(g["ipm_iters"].mean())
+    ok_cold = float((g["status"] == 0).mean())
+
+    # secondary measurements (not `value`): warm-started RTI; multi-GPU without the gather
+    run(2, False, False)
+    dt_warm, kernel_ms_warm = timed(args.steps, False, False, with_events=True)
+    gw = solver.get(B)
+    n_ipm_warm = float(gw["ipm_iters"].mean())
+    dt_nogather = None
+    if world > 1:
+        run(2, True, False)
+        dt_nogather, _ = timed(args.steps, True, False)
+
+    total_solves = world * B * args.steps
+    value = total_solves / dt_main
+    out = {
+        "metric": "batched NMPC SQP-RTI solves/sec (N=40, fp64)",
+        "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt_main / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"config 2: {B} path-tracking OCP instances per GPU, N={N}, dt=0.35, "
+                               "cold SQP-RTI (one QP) per step, seed 0x5EED0001",
+                   "batch_per_gpu": B, "horizon": N, "parallelism": f"dp{world} (instances sharded, "
+                   "RCCL all-gather of control records)" if world > 1 else "single GPU"},
+        "mean_ipm_iters": n_ipm_cold, "converged_frac": ok_cold,
+    }
+    if kernel_ms:
+        fl = flops_per_solve(N, n_ipm_cold) * B
+        by = bytes_per_solve(N, False) * B
+        tf = fl / (kernel_ms * 1e-3) / 1e12
+        out["roofline"] = {
+            "bound": "fp64_valu", "kernel": "nmpc_solve_kernel", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+            "kernel_ms": kernel_ms, "flops_per_solve": flops_per_solve(N, n_ipm_cold),
+            "hbm": {"bound": "hbm", "achieved": by / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": by / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "bytes_per_solve": bytes_per_solve(N, False)},
+        }
+    out["warm"] = {"value": total_solves / dt_warm, "ms_per_step": 1e3 * dt_warm / args.steps,
+                   "kernel_ms": kernel_ms_warm, "mean_ipm_iters": n_ipm_warm}
+    if dt_nogather:
+        out["multi_gpu"] = {"with_gather": value, "without_gather": total_solves / dt_nogather}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(N)
+    if rank == 0:
+        print(json.dumps(out))
+    solver.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,121 @@
+/*
+ * nmpc.h -- C ABI of the MI355X batched path-tracking NMPC solver (libnmpc_hip.so).
+ *
+ * Drop-in boundary for the reference's solver path.  The reference binds the
+ * acados-generated C API (opaque capsule + ocp_nlp_* setters/getters), one OCP
+ * instance per capsule; those structs are not reproducible (acados headers are
+ * not part of the reference tree), so this ABI offers the same operations on a
+ * BATCH of independent instances held by one handle.  Each entry point names the
+ * reference call it replaces.  All functions return 0 (NMPC_OK) or a negative
+ * NMPC_E* code; none throws.  A handle is externally synchronised (one caller at
+ * a time, like the reference's process-wide static solver,
+ * src/PathTrackingSys.cpp:59); distinct handles are independent.
+ *
+ * Host arrays are caller-owned, row-major, double unless stated:
+ *   state  x0[B][6]   = x, y, psi, vel, delta, throttle         (include/mpc_local_planner/types.h:39-41)
+ *   params p [B][6]   = c0, c1, c2, c3, pitch, v_ref            (AcadosPathTracking.h:31-34)
+ *   x     [B][N+1][6], u [B][N][2] = deltaDot, throttleDot      (types.h:80)
+ * Per-instance status uses acados numbering: 0 success, 1 NaN, 2 max iterations
+ * (SQP mode), 4 QP failure.
+ */
+#ifndef NMPC_H
+#define NMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NMPC_OK 0
+#define NMPC_EINVAL (-1)   /* bad argument (null pointer, B > capacity, N out of range ...) */
+#define NMPC_EHIP (-2)     /* a HIP runtime call failed; see nmpc_last_error() */
+#define NMPC_ENOMEM (-3)
+
+#define NMPC_MODE_RTI 0    /* nlp_solver_type SQP_RTI (config/mpc_params.yaml:38) */
+#define NMPC_MODE_SQP 1    /* nlp_solver_type SQP */
+
+typedef struct nmpc_config {
+    int N;              /* mpc_N   (config/mpc_params.yaml:35); 1 <= N <= 63 */
+    double dt;          /* mpc_dt  (:41) */
+    double wheelbase;   /* (:59) */
+    double W[7];        /* diag of ocp.cost.W (acados/mpcPathTracking.py:103) */
+    double lbu[2], ubu[2];  /* steering_angle_dot_range, throttle_dot_range (:56,:50) */
+    double lbx[2], ubx[2];  /* steering_angle_range, throttle_range (:53,:47), states 4,5 */
+    /* interior-point QP solver (replaces the HPIPM options of mpcPathTracking.py:123-127) */
+    int ipm_max_iter;
+    double ipm_mu0, ipm_thr0, ipm_tau, ipm_tol_mu, ipm_tol_lin;
+} nmpc_config;
+
+typedef struct nmpc_handle nmpc_handle;
+
+/* Reference defaults for everything but N and dt. */
+int nmpc_default_config(nmpc_config *cfg, int N, double dt);
+
+/* Replaces path_tracking_acados_create_capsule + _create_with_discretization
+ * (src/AcadosPathTracking.cpp:28-49) for `capacity` instances on HIP device `device`.
+ * All device memory, the stream and the iterate buffers are owned by the handle.
+ * Every instance starts "cold" (see nmpc_reset). */
+int nmpc_create(const nmpc_config *cfg, int capacity, int device, nmpc_handle **out);
+
+/* Replaces path_tracking_acados_free + _free_capsule (src/AcadosPathTracking.cpp:51-64). */
+int nmpc_destroy(nmpc_handle *h);
+
+/* Replaces Solver::setInitCondition: lbx0 = ubx0 = x0 (src/AcadosSolver.cpp:15-26). */
+int nmpc_set_x0(nmpc_handle *h, const double *x0, int B);
+
+/* Replaces PathTracking::setParams / path_tracking_acados_update_params for stages 0..N
+ * (src/AcadosPathTracking.cpp:17-24); the same p is used on every stage. */
+int nmpc_set_params(nmpc_handle *h, const double *p, int B);
+
+/* Same two inputs already resident in device memory (no copy; the pointers must stay valid
+ * until the solves that use them have completed).  No reference counterpart: the reference
+ * is host-only. */
+int nmpc_set_inputs_device(nmpc_handle *h, const double *d_x0, const double *d_p, int B);
+
+/* Per-instance cost weights W[B][7] / bounds bnd[B][8] = lbu0,lbu1,lbx4,lbx5,ubu0,ubu1,ubx4,ubx5
+ * (the reference bakes one set into generated code, mpcPathTracking.py:103-115; the generic
+ * acados setters ocp_nlp_cost_model_set / ocp_nlp_constraints_model_set are the counterpart).
+ * NULL restores the handle's config values for all instances. */
+int nmpc_set_weights(nmpc_handle *h, const double *W, int B);
+int nmpc_set_bounds(nmpc_handle *h, const double *bnd, int B);
+
+/* Replaces Solver::setInitGuess / reInit (src/AcadosSolver.cpp:8-13,78-92): instances with
+ * mask[i] != 0 (all if mask == NULL) start their next solve from x_k = x0, u_k = 0.
+ * Instances whose last solve failed are reset automatically, as the reference does. */
+int nmpc_reset(nmpc_handle *h, const uint8_t *mask, int B);
+
+/* Replaces path_tracking_acados_solve (src/AcadosPathTracking.cpp:26) for instances 0..B-1:
+ * NMPC_MODE_RTI = one SQP-RTI iteration (rti_phase 0, src/AcadosSolver.cpp:42-48);
+ * NMPC_MODE_SQP = up to max_iter iterations until the step is below tol.
+ * Asynchronous on the handle's stream; iterates stay on the device (warm start, no shift,
+ * src/PathTrackingSys.cpp:58-61). */
+int nmpc_solve(nmpc_handle *h, int B, int mode, int max_iter, double tol);
+
+/* Wait for all work queued on the handle. */
+int nmpc_sync(nmpc_handle *h);
+
+/* Replaces ocp_nlp_out_get "x"/"u" (src/AcadosSolver.cpp:51-54).  Any output may be NULL.
+ * Synchronises the handle's stream. */
+int nmpc_get(nmpc_handle *h, int B, double *x, double *u, int32_t *status, double *cost,
+             int32_t *ipm_iters, int32_t *sqp_iters);
+
+/* Per-instance control record [B][6]: u0.deltaDot, u0.throttleDot, x[1].delta, x[1].throttle
+ * (what src/RosMpc.cpp:82-86 sends to the car), cost, status + 16*ipm_iters. */
+int nmpc_get_controls(nmpc_handle *h, int B, double *ctrl);
+
+/* Device-side views for zero-copy consumers (RCCL all-gather of the control records,
+ * timing with HIP events).  which: 0 control records [cap][6], 1 iterate [cap][N+1][8]
+ * (X,Y,psi,v,delta,thr,u0,u1 per node), 2 status int32[cap]. */
+void *nmpc_device_ptr(nmpc_handle *h, int which);
+void *nmpc_stream(nmpc_handle *h);       /* hipStream_t */
+int nmpc_capacity(const nmpc_handle *h);
+int nmpc_horizon(const nmpc_handle *h);
+
+/* Text of the last HIP error seen by this thread ("" if none). */
+const char *nmpc_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMPC_H */

@@ -1,0 +1,32 @@
+"""In-tree build of the HIP library (gfx950 only).  `python -m mpc_local_planner_amd.build`."""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB = os.path.join(_HERE, "libnmpc_hip.so")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_hip(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, f) for f in ("nmpc_hip.hip", "nmpc_wave_solver.h")]
+    srcs.append(os.path.join(_HERE, "..", "include", "nmpc.h"))
+    if force or _stale(LIB, srcs):
+        cmd = [HIPCC] + FLAGS + ["-o", LIB, srcs[0]]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        subprocess.check_call(cmd, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_hip(force=True, verbose=True))

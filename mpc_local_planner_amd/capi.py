@@ -1,0 +1,188 @@
+"""ctypes binding of the C ABI in include/nmpc.h (libnmpc_hip.so, gfx950).
+
+There is no CPU fallback: if the HIP library is missing this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnmpc_hip.so")
+
+MODE_RTI, MODE_SQP = 0, 1
+OK, EINVAL, EHIP, ENOMEM = 0, -1, -2, -3
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("N", C.c_int), ("dt", C.c_double), ("wheelbase", C.c_double),
+        ("W", C.c_double * 7),
+        ("lbu", C.c_double * 2), ("ubu", C.c_double * 2),
+        ("lbx", C.c_double * 2), ("ubx", C.c_double * 2),
+        ("ipm_max_iter", C.c_int), ("ipm_mu0", C.c_double), ("ipm_thr0", C.c_double),
+        ("ipm_tau", C.c_double), ("ipm_tol_mu", C.c_double), ("ipm_tol_lin", C.c_double),
+    ]
+
+
+EXPORTS = [
+    "nmpc_default_config", "nmpc_create", "nmpc_destroy", "nmpc_set_x0", "nmpc_set_params",
+    "nmpc_set_inputs_device", "nmpc_set_weights", "nmpc_set_bounds", "nmpc_reset", "nmpc_solve",
+    "nmpc_sync", "nmpc_get", "nmpc_get_controls", "nmpc_device_ptr", "nmpc_stream",
+    "nmpc_capacity", "nmpc_horizon", "nmpc_last_error",
+]
+
+_lib = None
+
+
+class NmpcError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libnmpc_hip.so (built in-tree by mpc_local_planner_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NmpcError(
+            f"{LIB_PATH} is missing: build it with `python -m mpc_local_planner_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback.")
+    l = C.CDLL(LIB_PATH)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
+    l.nmpc_default_config.argtypes = [C.POINTER(Config), C.c_int, C.c_double]
+    l.nmpc_create.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.POINTER(vp)]
+    l.nmpc_destroy.argtypes = [vp]
+    l.nmpc_set_x0.argtypes = [vp, dp, C.c_int]
+    l.nmpc_set_params.argtypes = [vp, dp, C.c_int]
+    l.nmpc_set_inputs_device.argtypes = [vp, vp, vp, C.c_int]
+    l.nmpc_set_weights.argtypes = [vp, dp, C.c_int]
+    l.nmpc_set_bounds.argtypes = [vp, dp, C.c_int]
+    l.nmpc_reset.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int]
+    l.nmpc_solve.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double]
+    l.nmpc_sync.argtypes = [vp]
+    l.nmpc_get.argtypes = [vp, C.c_int, dp, dp, ip, dp, ip, ip]
+    l.nmpc_get_controls.argtypes = [vp, C.c_int, dp]
+    l.nmpc_device_ptr.argtypes = [vp, C.c_int]
+    l.nmpc_device_ptr.restype = vp
+    l.nmpc_stream.argtypes = [vp]
+    l.nmpc_stream.restype = vp
+    l.nmpc_capacity.argtypes = [vp]
+    l.nmpc_horizon.argtypes = [vp]
+    l.nmpc_last_error.restype = C.c_char_p
+    _lib = l
+    return l
+
+
+def check(rc, what):
+    if rc != OK:
+        raise NmpcError(f"{what} failed with code {rc}: {lib().nmpc_last_error().decode()}")
+
+
+def default_config(N=40, dt=0.35, **over):
+    cfg = Config()
+    check(lib().nmpc_default_config(C.byref(cfg), N, dt), "nmpc_default_config")
+    for k, v in over.items():
+        cur = getattr(cfg, k)
+        if hasattr(cur, "__len__"):
+            for i, e in enumerate(v):
+                cur[i] = e
+        else:
+            setattr(cfg, k, v)
+    return cfg
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class BatchSolver:
+    """Thin object wrapper over one nmpc_handle (a batch of independent OCP instances)."""
+
+    def __init__(self, cfg=None, capacity=1, device=0, **over):
+        self.cfg = cfg if cfg is not None else default_config(**over)
+        self.capacity = capacity
+        self.N = self.cfg.N
+        self._h = C.c_void_p()
+        check(lib().nmpc_create(C.byref(self.cfg), capacity, device, C.byref(self._h)), "nmpc_create")
+
+    def close(self):
+        if self._h:
+            lib().nmpc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_x0(self, x0):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1, 6)
+        check(lib().nmpc_set_x0(self._h, _dp(x0), x0.shape[0]), "nmpc_set_x0")
+
+    def set_params(self, p):
+        p = np.ascontiguousarray(p, dtype=np.float64).reshape(-1, 6)
+        check(lib().nmpc_set_params(self._h, _dp(p), p.shape[0]), "nmpc_set_params")
+
+    def set_inputs_device(self, d_x0, d_p, B):
+        check(lib().nmpc_set_inputs_device(self._h, d_x0, d_p, B), "nmpc_set_inputs_device")
+
+    def set_weights(self, W=None):
+        if W is None:
+            check(lib().nmpc_set_weights(self._h, None, self.capacity), "nmpc_set_weights")
+        else:
+            W = np.ascontiguousarray(W, dtype=np.float64).reshape(-1, 7)
+            check(lib().nmpc_set_weights(self._h, _dp(W), W.shape[0]), "nmpc_set_weights")
+
+    def set_bounds(self, bnd=None):
+        if bnd is None:
+            check(lib().nmpc_set_bounds(self._h, None, self.capacity), "nmpc_set_bounds")
+        else:
+            bnd = np.ascontiguousarray(bnd, dtype=np.float64).reshape(-1, 8)
+            check(lib().nmpc_set_bounds(self._h, _dp(bnd), bnd.shape[0]), "nmpc_set_bounds")
+
+    def reset(self, mask=None, B=None):
+        if mask is None:
+            check(lib().nmpc_reset(self._h, None, B or self.capacity), "nmpc_reset")
+        else:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+            check(lib().nmpc_reset(self._h, mask.ctypes.data_as(C.POINTER(C.c_uint8)), mask.shape[0]),
+                  "nmpc_reset")
+
+    def solve(self, B=None, mode=MODE_RTI, max_iter=1, tol=1e-6):
+        check(lib().nmpc_solve(self._h, B or self.capacity, mode, max_iter, tol), "nmpc_solve")
+
+    def sync(self):
+        check(lib().nmpc_sync(self._h), "nmpc_sync")
+
+    def get(self, B=None):
+        B = B or self.capacity
+        x = np.zeros((B, self.N + 1, 6))
+        u = np.zeros((B, self.N, 2))
+        status = np.zeros(B, dtype=np.int32)
+        cost = np.zeros(B)
+        it = np.zeros(B, dtype=np.int32)
+        sq = np.zeros(B, dtype=np.int32)
+        check(lib().nmpc_get(self._h, B, _dp(x), _dp(u), _ip(status), _dp(cost), _ip(it), _ip(sq)), "nmpc_get")
+        return dict(x=x, u=u, status=status, cost=cost, ipm_iters=it, sqp_iters=sq)
+
+    def get_controls(self, B=None):
+        B = B or self.capacity
+        c = np.zeros((B, 6))
+        check(lib().nmpc_get_controls(self._h, B, _dp(c)), "nmpc_get_controls")
+        return c
+
+    def device_ptr(self, which):
+        return lib().nmpc_device_ptr(self._h, which)
+
+    def stream(self):
+        return lib().nmpc_stream(self._h)

@@ -1,0 +1,396 @@
+// nmpc_hip.hip -- gfx950 kernels and the C ABI (include/nmpc.h) of the batched
+// path-tracking NMPC solver.  One 64-lane wavefront (= one 64-thread workgroup)
+// per OCP instance; see nmpc_wave_solver.h for the in-wave work mapping.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#define NMPC_DEV __device__ __forceinline__
+#include "nmpc_wave_solver.h"
+
+#include "../../include/nmpc.h"
+
+namespace {
+
+// ------------------------------------------------------------------ device side
+
+struct GpuWave {
+    double *lds_;
+    __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }
+    __device__ __forceinline__ double *lds() { return lds_; }
+    // exchange through LDS between lanes of the single wave of this workgroup
+    __device__ __forceinline__ void sync() { __syncthreads(); }
+    // ordering that lock-step execution of one wave already provides
+    __device__ __forceinline__ void sync_lockstep() {}
+    __device__ __forceinline__ double readlane(double v, int src)
+    {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+        return __hiloint2double(hi, lo);
+    }
+    __device__ __forceinline__ double shfl_down1(double v) { return __shfl_down(v, 1, 64); }
+    __device__ __forceinline__ double sum(double v)
+    {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    }
+    __device__ __forceinline__ double max(double v)
+    {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+        return v;
+    }
+    // reciprocal to ~1 ulp: hardware seed + two Newton steps (no div_scale/div_fixup sequence;
+    // operands here are never subnormal or huge)
+    __device__ __forceinline__ double rcp(double x)
+    {
+        double y = __builtin_amdgcn_rcp(x);
+        y = fma(fma(-x, y, 1.0), y, y);
+        y = fma(fma(-x, y, 1.0), y, y);
+        return y;
+    }
+};
+
+struct KernelArgs {
+    nmpcw::Problem pb;
+    int B;
+    const double *x0, *p, *W, *bnd;
+    double *traj, *ctrl, *cost;
+    int *status, *iters, *sqp_iters;
+    unsigned char *reset;
+};
+
+__global__ void __launch_bounds__(64, 2) nmpc_solve_kernel(KernelArgs a)
+{
+    extern __shared__ double lds[];
+    const int inst = (int)blockIdx.x;
+    if (inst >= a.B) return;
+    nmpcw::InstanceIO io;
+    io.x0 = a.x0 + (size_t)inst * 6;
+    io.p = a.p + (size_t)inst * 6;
+    io.W = a.W + (size_t)inst * 7;
+    io.bnd = a.bnd + (size_t)inst * 8;
+    io.traj = a.traj + (size_t)inst * (a.pb.N + 1) * 8;
+    io.ctrl = a.ctrl + (size_t)inst * 6;
+    io.status = a.status + inst;
+    io.iters = a.iters + inst;
+    io.sqp_iters = a.sqp_iters + inst;
+    io.cost = a.cost + inst;
+    io.cold = a.reset[inst];
+    GpuWave w{lds};
+    nmpcw::solve_instance(w, a.pb, io);
+    // failed instances restart cold next time (reference: reInit on status != 0,
+    // src/AcadosSolver.cpp:56-59); successful ones keep their iterate (warm start)
+    if (threadIdx.x == 0) a.reset[inst] = (*io.status != 0 && *io.status != 2) ? 1 : 0;
+}
+
+__global__ void nmpc_fill_rows_kernel(double *dst, int rows, int width, const double *vals8)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * width) dst[i] = vals8[i % width];
+}
+
+__global__ void nmpc_set_reset_kernel(unsigned char *dst, const unsigned char *mask, int B)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) dst[i] = mask ? (mask[i] ? 1 : dst[i]) : 1;
+}
+
+thread_local char g_err[256] = "";
+
+bool hip_ok(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return true;
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return false;
+}
+
+#define HIP_TRY(call)                                   \
+    do {                                                \
+        if (!hip_ok((call), #call)) return NMPC_EHIP;   \
+    } while (0)
+
+}  // namespace
+
+// ------------------------------------------------------------------ host side
+
+struct nmpc_handle {
+    nmpc_config cfg;
+    int capacity;
+    int device;
+    hipStream_t stream;
+    double *d_x0, *d_p, *d_W, *d_bnd, *d_traj, *d_ctrl, *d_cost, *d_tmp;
+    int *d_status, *d_iters, *d_sqp;
+    unsigned char *d_reset, *d_mask;
+    const double *in_x0, *in_p;   // what the kernel reads (own buffers or caller's device buffers)
+    std::vector<double> h_traj;
+};
+
+extern "C" {
+
+const char *nmpc_last_error(void) { return g_err; }
+
+int nmpc_default_config(nmpc_config *c, int N, double dt)
+{
+    if (!c) return NMPC_EINVAL;
+    static const double W[7] = {5, 5, 10, 0.01, 0.1, 0.5, 0.1};
+    memset(c, 0, sizeof(*c));
+    c->N = N;
+    c->dt = dt;
+    c->wheelbase = 2.65;
+    memcpy(c->W, W, sizeof(W));
+    c->lbu[0] = -80.0; c->ubu[0] = 80.0;
+    c->lbu[1] = -0.33; c->ubu[1] = 0.33;
+    c->lbx[0] = -0.57; c->ubx[0] = 0.57;
+    c->lbx[1] = -1.0;  c->ubx[1] = 1.0;
+    c->ipm_max_iter = 50;
+    c->ipm_mu0 = 100.0;
+    c->ipm_thr0 = 0.5;
+    c->ipm_tau = 0.995;
+    c->ipm_tol_mu = 1e-10;
+    c->ipm_tol_lin = 1e-10;
+    return NMPC_OK;
+}
+
+static int fill_defaults(nmpc_handle *h, bool weights, bool bounds)
+{
+    const int cap = h->capacity;
+    double v[16];
+    if (weights) {
+        HIP_TRY(hipMemcpyAsync(h->d_tmp, h->cfg.W, sizeof(double) * 7, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(nmpc_fill_rows_kernel, dim3((cap * 7 + 255) / 256), dim3(256), 0, h->stream,
+                           h->d_W, cap, 7, h->d_tmp);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    if (bounds) {
+        v[0] = h->cfg.lbu[0]; v[1] = h->cfg.lbu[1]; v[2] = h->cfg.lbx[0]; v[3] = h->cfg.lbx[1];
+        v[4] = h->cfg.ubu[0]; v[5] = h->cfg.ubu[1]; v[6] = h->cfg.ubx[0]; v[7] = h->cfg.ubx[1];
+        HIP_TRY(hipMemcpyAsync(h->d_tmp, v, sizeof(double) * 8, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(nmpc_fill_rows_kernel, dim3((cap * 8 + 255) / 256), dim3(256), 0, h->stream,
+                           h->d_bnd, cap, 8, h->d_tmp);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return NMPC_OK;
+}
+
+int nmpc_create(const nmpc_config *cfg, int capacity, int device, nmpc_handle **out)
+{
+    if (!cfg || !out || capacity <= 0) return NMPC_EINVAL;
+    if (cfg->N < 1 || cfg->N > 63 || !(cfg->dt > 0.0) || !(cfg->wheelbase > 0.0)) return NMPC_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return NMPC_EINVAL;
+    HIP_TRY(hipSetDevice(device));
+    nmpc_handle *h = new (std::nothrow) nmpc_handle();
+    if (!h) return NMPC_ENOMEM;
+    h->cfg = *cfg;
+    h->capacity = capacity;
+    h->device = device;
+    const size_t cap = (size_t)capacity, N1 = (size_t)cfg->N + 1;
+    struct { void **p; size_t bytes; } allocs[] = {
+        {(void **)&h->d_x0, cap * 6 * sizeof(double)},   {(void **)&h->d_p, cap * 6 * sizeof(double)},
+        {(void **)&h->d_W, cap * 7 * sizeof(double)},    {(void **)&h->d_bnd, cap * 8 * sizeof(double)},
+        {(void **)&h->d_traj, cap * N1 * 8 * sizeof(double)}, {(void **)&h->d_ctrl, cap * 6 * sizeof(double)},
+        {(void **)&h->d_cost, cap * sizeof(double)},     {(void **)&h->d_tmp, 16 * sizeof(double)},
+        {(void **)&h->d_status, cap * sizeof(int)},      {(void **)&h->d_iters, cap * sizeof(int)},
+        {(void **)&h->d_sqp, cap * sizeof(int)},         {(void **)&h->d_reset, cap},
+        {(void **)&h->d_mask, cap},
+    };
+    for (auto &a : allocs) *a.p = nullptr;
+    bool ok = hip_ok(hipStreamCreate(&h->stream), "hipStreamCreate");
+    for (auto &a : allocs) {
+        if (!ok) break;
+        ok = hip_ok(hipMalloc(a.p, a.bytes), "hipMalloc");
+        if (ok) ok = hip_ok(hipMemsetAsync(*a.p, 0, a.bytes, h->stream), "hipMemsetAsync");
+    }
+    if (ok) ok = hip_ok(hipMemsetAsync(h->d_reset, 1, cap, h->stream), "hipMemsetAsync");
+    if (ok) ok = fill_defaults(h, true, true) == NMPC_OK;
+    if (ok) {
+        const int lds_bytes = nmpcw::lds_doubles(cfg->N) * (int)sizeof(double);
+        if (lds_bytes > 64 * 1024)
+            ok = hip_ok(hipFuncSetAttribute((const void *)nmpc_solve_kernel,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes),
+                        "hipFuncSetAttribute");
+    }
+    if (!ok) {
+        for (auto &a : allocs) if (*a.p) (void)hipFree(*a.p);
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+        delete h;
+        return NMPC_EHIP;
+    }
+    h->in_x0 = h->d_x0;
+    h->in_p = h->d_p;
+    *out = h;
+    return NMPC_OK;
+}
+
+int nmpc_destroy(nmpc_handle *h)
+{
+    if (!h) return NMPC_EINVAL;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    void *ptrs[] = {h->d_x0, h->d_p, h->d_W, h->d_bnd, h->d_traj, h->d_ctrl, h->d_cost, h->d_tmp,
+                    h->d_status, h->d_iters, h->d_sqp, h->d_reset, h->d_mask};
+    int rc = NMPC_OK;
+    for (void *p : ptrs)
+        if (p && !hip_ok(hipFree(p), "hipFree")) rc = NMPC_EHIP;
+    if (!hip_ok(hipStreamDestroy(h->stream), "hipStreamDestroy")) rc = NMPC_EHIP;
+    delete h;
+    return rc;
+}
+
+static int upload(nmpc_handle *h, double *dst, const double *src, int B, int width)
+{
+    if (!h || !src || B <= 0 || B > h->capacity) return NMPC_EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * (size_t)B * width, hipMemcpyHostToDevice, h->stream));
+    // the caller's buffer may be reused as soon as we return
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return NMPC_OK;
+}
+
+int nmpc_set_x0(nmpc_handle *h, const double *x0, int B)
+{
+    const int rc = upload(h, h ? h->d_x0 : nullptr, x0, B, 6);
+    if (rc == NMPC_OK) h->in_x0 = h->d_x0;
+    return rc;
+}
+
+int nmpc_set_params(nmpc_handle *h, const double *p, int B)
+{
+    const int rc = upload(h, h ? h->d_p : nullptr, p, B, 6);
+    if (rc == NMPC_OK) h->in_p = h->d_p;
+    return rc;
+}
+
+int nmpc_set_inputs_device(nmpc_handle *h, const double *d_x0, const double *d_p, int B)
+{
+    if (!h || !d_x0 || !d_p || B <= 0 || B > h->capacity) return NMPC_EINVAL;
+    h->in_x0 = d_x0;
+    h->in_p = d_p;
+    return NMPC_OK;
+}
+
+int nmpc_set_weights(nmpc_handle *h, const double *W, int B)
+{
+    if (!h) return NMPC_EINVAL;
+    if (!W) { HIP_TRY(hipSetDevice(h->device)); return fill_defaults(h, true, false); }
+    return upload(h, h->d_W, W, B, 7);
+}
+
+int nmpc_set_bounds(nmpc_handle *h, const double *bnd, int B)
+{
+    if (!h) return NMPC_EINVAL;
+    if (!bnd) { HIP_TRY(hipSetDevice(h->device)); return fill_defaults(h, false, true); }
+    return upload(h, h->d_bnd, bnd, B, 8);
+}
+
+int nmpc_reset(nmpc_handle *h, const uint8_t *mask, int B)
+{
+    if (!h || B <= 0 || B > h->capacity) return NMPC_EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    if (mask) HIP_TRY(hipMemcpyAsync(h->d_mask, mask, (size_t)B, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(nmpc_set_reset_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->d_reset,
+                       mask ? h->d_mask : nullptr, B);
+    HIP_TRY(hipGetLastError());
+    if (mask) HIP_TRY(hipStreamSynchronize(h->stream));
+    return NMPC_OK;
+}
+
+int nmpc_solve(nmpc_handle *h, int B, int mode, int max_iter, double tol)
+{
+    if (!h || B <= 0 || B > h->capacity) return NMPC_EINVAL;
+    if (mode != NMPC_MODE_RTI && mode != NMPC_MODE_SQP) return NMPC_EINVAL;
+    if (mode == NMPC_MODE_SQP && max_iter < 1) return NMPC_EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    KernelArgs a;
+    a.pb.N = h->cfg.N;
+    a.pb.dt = h->cfg.dt;
+    a.pb.inv_wheelbase = 1.0 / h->cfg.wheelbase;
+    a.pb.ipm_max_iter = h->cfg.ipm_max_iter;
+    a.pb.mu0 = h->cfg.ipm_mu0;
+    a.pb.thr0 = h->cfg.ipm_thr0;
+    a.pb.tau = h->cfg.ipm_tau;
+    a.pb.tol_mu = h->cfg.ipm_tol_mu;
+    a.pb.tol_lin = h->cfg.ipm_tol_lin;
+    a.pb.sqp_max_iter = (mode == NMPC_MODE_RTI) ? 1 : max_iter;
+    a.pb.sqp_tol = tol;
+    a.B = B;
+    a.x0 = h->in_x0; a.p = h->in_p; a.W = h->d_W; a.bnd = h->d_bnd;
+    a.traj = h->d_traj; a.ctrl = h->d_ctrl; a.cost = h->d_cost;
+    a.status = h->d_status; a.iters = h->d_iters; a.sqp_iters = h->d_sqp;
+    a.reset = h->d_reset;
+    const size_t lds_bytes = (size_t)nmpcw::lds_doubles(h->cfg.N) * sizeof(double);
+    hipLaunchKernelGGL(nmpc_solve_kernel, dim3(B), dim3(64), lds_bytes, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    return NMPC_OK;
+}
+
+int nmpc_sync(nmpc_handle *h)
+{
+    if (!h) return NMPC_EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return NMPC_OK;
+}
+
+int nmpc_get(nmpc_handle *h, int B, double *x, double *u, int32_t *status, double *cost,
+             int32_t *ipm_iters, int32_t *sqp_iters)
+{
+    if (!h || B <= 0 || B > h->capacity) return NMPC_EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t N = (size_t)h->cfg.N, N1 = N + 1;
+    if (x || u) {
+        h->h_traj.resize((size_t)B * N1 * 8);
+        HIP_TRY(hipMemcpyAsync(h->h_traj.data(), h->d_traj, sizeof(double) * h->h_traj.size(),
+                               hipMemcpyDeviceToHost, h->stream));
+    }
+    if (status) HIP_TRY(hipMemcpyAsync(status, h->d_status, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    if (cost) HIP_TRY(hipMemcpyAsync(cost, h->d_cost, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    if (ipm_iters) HIP_TRY(hipMemcpyAsync(ipm_iters, h->d_iters, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    if (sqp_iters) HIP_TRY(hipMemcpyAsync(sqp_iters, h->d_sqp, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (x || u) {
+        const double *t = h->h_traj.data();
+        for (size_t b = 0; b < (size_t)B; ++b)
+            for (size_t k = 0; k < N1; ++k) {
+                const double *r = t + (b * N1 + k) * 8;
+                if (x) memcpy(x + (b * N1 + k) * 6, r, sizeof(double) * 6);
+                if (u && k < N) { u[(b * N + k) * 2] = r[6]; u[(b * N + k) * 2 + 1] = r[7]; }
+            }
+    }
+    return NMPC_OK;
+}
+
+int nmpc_get_controls(nmpc_handle *h, int B, double *ctrl)
+{
+    if (!h || !ctrl || B <= 0 || B > h->capacity) return NMPC_EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(ctrl, h->d_ctrl, sizeof(double) * (size_t)B * 6, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return NMPC_OK;
+}
+
+void *nmpc_device_ptr(nmpc_handle *h, int which)
+{
+    if (!h) return nullptr;
+    switch (which) {
+        case 0: return h->d_ctrl;
+        case 1: return h->d_traj;
+        case 2: return h->d_status;
+        default: return nullptr;
+    }
+}
+
+void *nmpc_stream(nmpc_handle *h) { return h ? (void *)h->stream : nullptr; }
+int nmpc_capacity(const nmpc_handle *h) { return h ? h->capacity : NMPC_EINVAL; }
+int nmpc_horizon(const nmpc_handle *h) { return h ? h->cfg.N : NMPC_EINVAL; }
+
+}  // extern "C"

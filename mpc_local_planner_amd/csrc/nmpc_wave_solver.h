@@ -66,13 +66,38 @@ constexpr int S_D = 18;         // r_b[6] -> dz_aff[8] -> dG[4] -> dz_cor[8]
 constexpr int S_TAB = 0;        // input view
 constexpr int S_G = 8;
 constexpr int X_P = 0, X_PV = 36, X_M = 44, X_V = 92, X_H = 100, X_XN = 120, X_SIZE = 128;
-NMPC_DEV constexpr int lds_doubles(int N) { return N * (BA_STRIDE + SLOT) + X_SIZE; }
+constexpr int lds_doubles(int N) { return N * (BA_STRIDE + SLOT) + X_SIZE; }
 
 struct Lin {        // per-node linearisation kept in stage-layout registers
     double Q00, Q01, Q02;   // variable entries of the GN Hessian (X,X) (X,Y) (X,psi)
     double g[8];            // gradient [u0,u1,X,Y,psi,v,delta,thr]
     double rb[6];           // dynamics gap phi(x_k,u_k) - x_{k+1}
 };
+
+
+// sin/cos/tan for the bounded angles of this model (|x| < ~1e5): two-constant Cody-Waite
+// reduction with fma and the classic degree-13/14 minimax kernels (errors < 1 ulp on the
+// reduced argument).  Replaces the generic libm routines, whose huge-argument paths cost
+// hundreds of VGPRs and scratch on gfx950 (hard part 3).
+NMPC_DEV void sincos_bounded(double x, double *sn, double *cs)
+{
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632679489655800e+00, x);
+    r = fma(-k, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    const double ps = fma(fma(fma(fma(fma(1.58969099521155010221e-10, z, -2.50507602534068634195e-08), z,
+                                          2.75573137070700676789e-06), z, -1.98412698298579493134e-04), z,
+                                  8.33333333332248946124e-03), z, -1.66666666666666324348e-01);
+    const double s = fma(r * z, ps, r);
+    const double pc = fma(fma(fma(fma(fma(-1.13596475577881948265e-11, z, 2.08757232129817482790e-09), z,
+                                          -2.75573143513906633035e-07), z, 2.48015872894767294178e-05), z,
+                                  -1.38888888888741095749e-03), z, 4.16666666666666019037e-02);
+    const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = ((int)k) & 3;
+    const double s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
+    *sn = (q & 2) ? -s1 : s1;
+    *cs = ((q + 1) & 2) ? -c1 : c1;
+}
 
 // ERK4 step with forward sensitivities of the kinematic bicycle, structure exploited:
 //   rows delta,thr of phi are exact integrators, columns X,Y of d(phi)/dx are unit vectors,
@@ -81,51 +106,47 @@ template <class W>
 NMPC_DEV void rk4_sens(const Problem &pb, const double *x, const double *u, double gp,
                        double *phi, double *aX, double *aY, double *aP, double *aV)
 {
+    // Explicit sparsity: d(v_s) has columns (v,thr,u1) only; d(psi_s)/d(psi) == 1.
     const double h = pb.dt, iL = pb.inv_wheelbase;
-    const double as[4] = {0.0, 0.5, 0.5, 1.0};
-    const double ws[4] = {1.0, 2.0, 2.0, 1.0};
-    double kX = 0, kY = 0, kP = 0, kV = 0;
-    double dKP[6] = {0, 0, 0, 0, 0, 0}, dKV[6] = {0, 0, 0, 0, 0, 0};
+    double kP = 0, kV = 0;
+    double kPv = 0, kPd = 0, kPt = 0, kP0 = 0, kP1 = 0;   // d kP / d(v,delta,thr,u0,u1)
+    double kVv = 0, kVt = 0, kV1 = 0;                     // d kV / d(v,thr,u1)
     double sX = 0, sY = 0, sP = 0, sV = 0;
-    double sdX[6], sdY[6], sdP[6], sdV[6];
-#pragma unroll
-    for (int m = 0; m < 6; ++m) sdX[m] = sdY[m] = sdP[m] = sdV[m] = 0.0;
+    double sXp = 0, sXv = 0, sXd = 0, sXt = 0, sX0 = 0, sX1 = 0;
+    double sYp = 0, sYv = 0, sYd = 0, sYt = 0, sY0 = 0, sY1 = 0;
+    double sPv = 0, sPd = 0, sPt = 0, sP0 = 0, sP1 = 0;
+    double sVv = 0, sVt = 0, sV1 = 0;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const double c = as[s] * h;
+        const double c = (s == 0) ? 0.0 : (s == 3 ? h : 0.5 * h);
+        const double wgt = (s == 0 || s == 3) ? 1.0 : 2.0;
         const double ps = x[2] + c * kP, vs = x[3] + c * kV;
         const double ds = x[4] + c * u[0], ts = x[5] + c * u[1];
-        double dps[6], dvs[6];
-#pragma unroll
-        for (int m = 0; m < 6; ++m) {
-            dps[m] = (m == 0 ? 1.0 : 0.0) + c * dKP[m];
-            dvs[m] = (m == 1 ? 1.0 : 0.0) + c * dKV[m];
-        }
-        const double sp = sin(ps), cp = cos(ps), td = tan(ds);
-        const double sec2 = 1.0 + td * td;
-        kX = vs * cp;
-        kY = vs * sp;
+        // sensitivities of the stage point
+        const double pv = c * kPv, pd = c * kPd, pt = c * kPt, p0 = c * kP0, p1 = c * kP1;  // d psi_s
+        const double vv = 1.0 + c * kVv, vt = c * kVt, v1 = c * kV1;                        // d v_s
+        double sp, cp, sd, cd;
+        sincos_bounded(ps, &sp, &cp);
+        sincos_bounded(ds, &sd, &cd);
+        const double td = sd / cd;
+        const double kX = vs * cp, kY = vs * sp;
         kP = vs * td * iL;
         kV = 5.0 * ts - 0.087 * vs + gp;
-        const double tl = td * iL, vl = vs * sec2 * iL;
-        double dKX[6], dKY[6];
-#pragma unroll
-        for (int m = 0; m < 6; ++m) {
-            const double dds = (m == 2 ? 1.0 : 0.0) + (m == 4 ? c : 0.0);
-            const double dts = (m == 3 ? 1.0 : 0.0) + (m == 5 ? c : 0.0);
-            dKX[m] = cp * dvs[m] - kY * dps[m];
-            dKY[m] = sp * dvs[m] + kX * dps[m];
-            dKP[m] = tl * dvs[m] + vl * dds;
-            dKV[m] = 5.0 * dts - 0.087 * dvs[m];
-            sdX[m] += ws[s] * dKX[m];
-            sdY[m] += ws[s] * dKY[m];
-            sdP[m] += ws[s] * dKP[m];
-            sdV[m] += ws[s] * dKV[m];
-        }
-        sX += ws[s] * kX;
-        sY += ws[s] * kY;
-        sP += ws[s] * kP;
-        sV += ws[s] * kV;
+        const double tl = td * iL, vl = vs * (1.0 + td * td) * iL;
+        // d kX = cp dv - kY dpsi ; d kY = sp dv + kX dpsi
+        const double kXp = -kY, kXv = cp * vv - kY * pv, kXd = -kY * pd, kXt = cp * vt - kY * pt,
+                     kX0 = -kY * p0, kX1 = cp * v1 - kY * p1;
+        const double kYp = kX, kYv = sp * vv + kX * pv, kYd = kX * pd, kYt = sp * vt + kX * pt,
+                     kY0 = kX * p0, kY1 = sp * v1 + kX * p1;
+        // d kP = tl dv + vl d(delta_s),  d(delta_s) = e_delta + c e_u0
+        kPv = tl * vv; kPd = vl; kPt = tl * vt; kP0 = vl * c; kP1 = tl * v1;
+        // d kV = 5 d(thr_s) - 0.087 dv,  d(thr_s) = e_thr + c e_u1
+        kVv = -0.087 * vv; kVt = 5.0 - 0.087 * vt; kV1 = 5.0 * c - 0.087 * v1;
+        sX += wgt * kX; sY += wgt * kY; sP += wgt * kP; sV += wgt * kV;
+        sXp += wgt * kXp; sXv += wgt * kXv; sXd += wgt * kXd; sXt += wgt * kXt; sX0 += wgt * kX0; sX1 += wgt * kX1;
+        sYp += wgt * kYp; sYv += wgt * kYv; sYd += wgt * kYd; sYt += wgt * kYt; sY0 += wgt * kY0; sY1 += wgt * kY1;
+        sPv += wgt * kPv; sPd += wgt * kPd; sPt += wgt * kPt; sP0 += wgt * kP0; sP1 += wgt * kP1;
+        sVv += wgt * kVv; sVt += wgt * kVt; sV1 += wgt * kV1;
     }
     const double h6 = h / 6.0;
     phi[0] = x[0] + h6 * sX;
@@ -134,16 +155,12 @@ NMPC_DEV void rk4_sens(const Problem &pb, const double *x, const double *u, doub
     phi[3] = x[3] + h6 * sV;
     phi[4] = x[4] + h * u[0];
     phi[5] = x[5] + h * u[1];
-#pragma unroll
-    for (int m = 0; m < 6; ++m) {
-        aX[m] = h6 * sdX[m];
-        aY[m] = h6 * sdY[m];
-        aP[m] = (m == 0 ? 1.0 : 0.0) + h6 * sdP[m];
-        aV[m] = (m == 1 ? 1.0 : 0.0) + h6 * sdV[m];
-    }
+    // columns: psi, v, delta, thr, u0, u1
+    aX[0] = h6 * sXp; aX[1] = h6 * sXv; aX[2] = h6 * sXd; aX[3] = h6 * sXt; aX[4] = h6 * sX0; aX[5] = h6 * sX1;
+    aY[0] = h6 * sYp; aY[1] = h6 * sYv; aY[2] = h6 * sYd; aY[3] = h6 * sYt; aY[4] = h6 * sY0; aY[5] = h6 * sY1;
+    aP[0] = 1.0;      aP[1] = h6 * sPv; aP[2] = h6 * sPd; aP[3] = h6 * sPt; aP[4] = h6 * sP0; aP[5] = h6 * sP1;
+    aV[0] = 0.0;      aV[1] = 1.0 + h6 * sVv; aV[2] = 0.0; aV[3] = h6 * sVt; aV[4] = 0.0;     aV[5] = h6 * sV1;
 }
-
-NMPC_DEV double rcp_nr(double d) { return 1.0 / d; }
 
 template <class W>
 NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
@@ -164,7 +181,9 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
     for (int m = 0; m < 7; ++m) Wt[m] = io.W[m];
 #pragma unroll
     for (int m = 0; m < 4; ++m) { lb[m] = io.bnd[m]; ub[m] = io.bnd[4 + m]; }
-    const double gp = sin(par[4]) * 9.81;
+    double gp, gpc;
+    sincos_bounded(par[4], &gp, &gpc);
+    gp *= 9.81;
 
     // ---------------------------------------------------------------- iterate (stage layout)
     const bool has_node = lane <= N;       // lanes 0..N hold x_k
@@ -178,9 +197,8 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
         ub_[0] = (io.cold || !act) ? 0.0 : t[6];
         ub_[1] = (io.cold || !act) ? 0.0 : t[7];
     }
-    const double mu_ = act ? 1.0 : 0.0;                 // mask of input bounds
-    const double mx_ = (act && lane >= 1) ? 1.0 : 0.0;  // mask of state bounds (nodes 1..N-1)
-    const double msk[4] = {mu_, mu_, mx_, mx_};
+    const bool actx = act && lane >= 1;    // state bounds exist on nodes 1..N-1 only
+    const bool mq[4] = {act, act, actx, actx};
     const double mcount = (double)(4 * N + 4 * (N - 1));
 
     // entry-layout constants
@@ -290,19 +308,15 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
 
         // ------------------------------------------------------------ interior point (stage layout)
         // bounded variables of this node: u0,u1,delta,thr -> z index 0,1,6,7
-        double lo[4], up[4], tl[4], tu[4], ll[4], lu[4];
-        {
-            const double cur[4] = {ub_[0], ub_[1], xb[4], xb[5]};
+        double tl[4], tu[4], ll[4], lu[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                lo[q] = lb[q] - cur[q];
-                up[q] = ub[q] - cur[q];
-                const double a = fmax(-lo[q], pb.thr0), b = fmax(up[q], pb.thr0);
-                tl[q] = msk[q] != 0.0 ? a : 1.0;
-                tu[q] = msk[q] != 0.0 ? b : 1.0;
-                ll[q] = msk[q] != 0.0 ? pb.mu0 / a : 0.0;
-                lu[q] = msk[q] != 0.0 ? pb.mu0 / b : 0.0;
-            }
+        for (int q = 0; q < 4; ++q) {
+            const double cur = (q == 0) ? ub_[0] : (q == 1) ? ub_[1] : (q == 2) ? xb[4] : xb[5];
+            const double a = fmax(cur - lb[q], pb.thr0), b = fmax(ub[q] - cur, pb.thr0);
+            tl[q] = mq[q] ? a : 1.0;
+            tu[q] = mq[q] ? b : 1.0;
+            ll[q] = mq[q] ? pb.mu0 * w.rcp(a) : 0.0;
+            lu[q] = mq[q] ? pb.mu0 * w.rcp(b) : 0.0;
         }
         double z[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // QP iterate of this node [du0,du1,dX..dthr]
         double lin_scale = 1.0;
@@ -312,14 +326,12 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
             // ---- E-A: barrier system of this node
             double mu_loc = 0.0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) mu_loc += msk[q] * (tl[q] * ll[q] + tu[q] * lu[q]);
+            for (int q = 0; q < 4; ++q) mu_loc += tl[q] * ll[q] + tu[q] * lu[q];
             const double mu = w.sum(mu_loc) / mcount;
             if (!(mu == mu)) { qp_status = 1; break; }
             if (it > 0 && mu <= pb.tol_mu && lin_scale <= pb.tol_lin) { qp_status = 0; break; }
             if (it >= pb.ipm_max_iter) { qp_status = (mu <= 1e-8 && lin_scale <= 1e-8) ? 0 : 4; break; }
 
-            double rtl[4], rtu[4], rl[4], ru[4];
-            const double wv[4] = {z[0], z[1], z[6], z[7]};
             double G[8];
             G[0] = R00 * z[0] + L.g[0];
             G[1] = R11 * z[1] + L.g[1];
@@ -332,16 +344,18 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
             double gam[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                rtl[q] = msk[q] * (wv[q] - lo[q] - tl[q]);
-                rtu[q] = msk[q] * (up[q] - wv[q] - tu[q]);
-                rl[q] = ll[q] / tl[q];
-                ru[q] = lu[q] / tu[q];
-                gam[q] = rl[q] + ru[q];
+                const double cur = (q == 0) ? ub_[0] : (q == 1) ? ub_[1] : (q == 2) ? xb[4] : xb[5];
+                const double wv = (q == 0) ? z[0] : (q == 1) ? z[1] : (q == 2) ? z[6] : z[7];
+                const double rtl = mq[q] ? (wv - (lb[q] - cur) - tl[q]) : 0.0;
+                const double rtu = mq[q] ? ((ub[q] - cur) - wv - tu[q]) : 0.0;
+                const double rl = ll[q] * w.rcp(tl[q]), ru = lu[q] * w.rcp(tu[q]);
+                gam[q] = rl + ru;
+                const double gq = rl * rtl - ru * rtu;
+                if (q == 0) G[0] += gq;
+                if (q == 1) G[1] += gq;
+                if (q == 2) G[6] += gq;
+                if (q == 3) G[7] += gq;
             }
-            G[0] += rl[0] * rtl[0] - ru[0] * rtu[0];
-            G[1] += rl[1] * rtl[1] - ru[1] * rtu[1];
-            G[6] += rl[2] * rtl[2] - ru[2] * rtu[2];
-            G[7] += rl[3] * rtl[3] - ru[3] * rtu[3];
             if (act) {
                 double *sl = ldsSlot + lane * SLOT;
                 sl[S_TAB + 0] = gam[0]; sl[S_TAB + 1] = gam[1]; sl[S_TAB + 2] = gam[2]; sl[S_TAB + 3] = gam[3];
@@ -357,6 +371,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
             w.sync();
 
             // ---- sweep B: Riccati factorisation, entry layout, k = N-1 .. 0
+#pragma unroll 1
             for (int k = N - 1; k >= 0; --k) {
                 const double *ba = ldsBA + k * BA_STRIDE;
                 double *sl = ldsSlot + k * SLOT;
@@ -384,7 +399,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 if (ei < 2) ldsX[X_H + ej * 2 + ei] = Hv;               // rows u0,u1 of H
                 const double H00 = w.readlane(Hv, 0), H01 = w.readlane(Hv, 1), H11 = w.readlane(Hv, 9);
                 const double h0 = w.readlane(hj, 0), h1 = w.readlane(hj, 1);
-                const double rdet = rcp_nr(H00 * H11 - H01 * H01);
+                const double rdet = w.rcp(H00 * H11 - H01 * H01);
                 const double i00 = H11 * rdet, i01 = -H01 * rdet, i11 = H00 * rdet;
                 w.sync();
                 const double Hj0 = ldsX[X_H + ej * 2], Hj1 = ldsX[X_H + ej * 2 + 1];
@@ -414,6 +429,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 if (pass == 1) {
                     // backward vector sweep with the corrector right-hand side
                     double p6[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll 1
                     for (int k = N - 1; k >= 0; --k) {
                         const double *ba = ldsBA + k * BA_STRIDE;
                         double *sl = ldsSlot + k * SLOT;
@@ -439,6 +455,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 }
                 // forward sweep
                 double dx[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll 1
                 for (int k = 0; k < N; ++k) {
                     const double *ba = ldsBA + k * BA_STRIDE;
                     double *sl = ldsSlot + k * SLOT;
@@ -477,30 +494,40 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
 #pragma unroll
                     for (int m = 0; m < 8; ++m) dzl[m] = has_node ? src[m] : 0.0;
                 }
+                // residuals and ratios of this node at the current (unchanged) iterate
+                double rtl[4], rtu[4], itl[4], itu[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double cur = (q == 0) ? ub_[0] : (q == 1) ? ub_[1] : (q == 2) ? xb[4] : xb[5];
+                    const double wv = (q == 0) ? z[0] : (q == 1) ? z[1] : (q == 2) ? z[6] : z[7];
+                    rtl[q] = mq[q] ? (wv - (lb[q] - cur) - tl[q]) : 0.0;
+                    rtu[q] = mq[q] ? ((ub[q] - cur) - wv - tu[q]) : 0.0;
+                    itl[q] = w.rcp(tl[q]);
+                    itu[q] = w.rcp(tu[q]);
+                }
                 if (pass == 0) {
                     // E-B: affine step lengths, centring parameter, corrector right-hand side
 #pragma unroll
                     for (int m = 0; m < 8; ++m) dzs[m] = dzl[m];
-                    const double dw[4] = {dzl[0], dzl[1], dzl[6], dzl[7]};
-                    double a_loc = 1.0;
+                    double r_loc = 0.0;
                     double dtl[4], dtu[4], dll[4], dlu[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        dtl[q] = msk[q] * (dw[q] + rtl[q]);
-                        dtu[q] = msk[q] * (-dw[q] + rtu[q]);
-                        dll[q] = -ll[q] - rl[q] * dtl[q];
-                        dlu[q] = -lu[q] - ru[q] * dtu[q];
-                        if (dtl[q] < 0.0) a_loc = fmin(a_loc, -tl[q] / dtl[q]);
-                        if (dtu[q] < 0.0) a_loc = fmin(a_loc, -tu[q] / dtu[q]);
-                        if (dll[q] < 0.0) a_loc = fmin(a_loc, -ll[q] / dll[q]);
-                        if (dlu[q] < 0.0) a_loc = fmin(a_loc, -lu[q] / dlu[q]);
+                        const double dw = (q == 0) ? dzl[0] : (q == 1) ? dzl[1] : (q == 2) ? dzl[6] : dzl[7];
+                        dtl[q] = mq[q] ? (dw + rtl[q]) : 0.0;
+                        dtu[q] = mq[q] ? (-dw + rtu[q]) : 0.0;
+                        dll[q] = -ll[q] - ll[q] * itl[q] * dtl[q];
+                        dlu[q] = -lu[q] - lu[q] * itu[q] * dtu[q];
+                        // largest -d/v over the positive variables (step to the boundary = 1/that)
+                        r_loc = fmax(r_loc, fmax(-dtl[q] * itl[q], -dtu[q] * itu[q]));
+                        r_loc = fmax(r_loc, mq[q] ? fmax(1.0 + dtl[q] * itl[q], 1.0 + dtu[q] * itu[q]) : 0.0);
                     }
-                    const double a_aff = w.min(a_loc);
+                    const double a_aff = w.rcp(fmax(1.0, w.max(r_loc)));
                     double ma = 0.0;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        ma += msk[q] * ((tl[q] + a_aff * dtl[q]) * (ll[q] + a_aff * dll[q]) +
-                                        (tu[q] + a_aff * dtu[q]) * (lu[q] + a_aff * dlu[q]));
+                        ma += (tl[q] + a_aff * dtl[q]) * (ll[q] + a_aff * dll[q]) +
+                              (tu[q] + a_aff * dtu[q]) * (lu[q] + a_aff * dlu[q]);
                     mu_aff = w.sum(ma) / mcount;
                     const double sr = mu_aff / mu;
                     smu = sr * sr * sr * mu;
@@ -509,7 +536,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     for (int q = 0; q < 4; ++q) {
                         ctl[q] = smu - dtl[q] * dll[q];
                         ctu[q] = smu - dtu[q] * dlu[q];
-                        dG[q] = msk[q] * (-ctl[q] / tl[q] + ctu[q] / tu[q]);
+                        dG[q] = mq[q] ? (-ctl[q] * itl[q] + ctu[q] * itu[q]) : 0.0;
                     }
                     if (act) {
                         double *sl = ldsSlot + lane * SLOT;
@@ -521,21 +548,19 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     // E-C: combined direction, step length, update
 #pragma unroll
                     for (int m = 0; m < 8; ++m) dzs[m] += dzl[m];
-                    const double dw[4] = {dzs[0], dzs[1], dzs[6], dzs[7]};
-                    double a_loc = 1e300;
+                    double r_loc = 0.0;
                     double dtl[4], dtu[4], dll[4], dlu[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        dtl[q] = msk[q] * (dw[q] + rtl[q]);
-                        dtu[q] = msk[q] * (-dw[q] + rtu[q]);
-                        dll[q] = msk[q] * (ctl[q] / tl[q] - ll[q] - rl[q] * dtl[q]);
-                        dlu[q] = msk[q] * (ctu[q] / tu[q] - lu[q] - ru[q] * dtu[q]);
-                        if (dtl[q] < 0.0) a_loc = fmin(a_loc, -tl[q] / dtl[q]);
-                        if (dtu[q] < 0.0) a_loc = fmin(a_loc, -tu[q] / dtu[q]);
-                        if (dll[q] < 0.0) a_loc = fmin(a_loc, -ll[q] / dll[q]);
-                        if (dlu[q] < 0.0) a_loc = fmin(a_loc, -lu[q] / dlu[q]);
+                        const double dw = (q == 0) ? dzs[0] : (q == 1) ? dzs[1] : (q == 2) ? dzs[6] : dzs[7];
+                        dtl[q] = mq[q] ? (dw + rtl[q]) : 0.0;
+                        dtu[q] = mq[q] ? (-dw + rtu[q]) : 0.0;
+                        dll[q] = mq[q] ? (ctl[q] * itl[q] - ll[q] - ll[q] * itl[q] * dtl[q]) : 0.0;
+                        dlu[q] = mq[q] ? (ctu[q] * itu[q] - lu[q] - lu[q] * itu[q] * dtu[q]) : 0.0;
+                        r_loc = fmax(r_loc, fmax(-dtl[q] * itl[q], -dtu[q] * itu[q]));
+                        r_loc = fmax(r_loc, mq[q] ? fmax(-dll[q] * w.rcp(ll[q]), -dlu[q] * w.rcp(lu[q])) : 0.0);
                     }
-                    const double a_max = w.min(a_loc);
+                    const double a_max = w.rcp(w.max(r_loc));
                     const double tau = fmax(pb.tau, 1.0 - mu_aff);
                     const double alpha = fmin(1.0, tau * a_max);
 #pragma unroll
@@ -574,7 +599,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
             double sl = 0.0;
 #pragma unroll
             for (int m = 0; m < 8; ++m) sl = fmax(sl, fabs(z[m]));
-            const double step = -w.min(has_node ? -sl : 0.0);
+            const double step = w.max(has_node ? sl : 0.0);
             if (step <= pb.sqp_tol) { ++sqp_it; status = 0; break; }
             if (sqp_it + 1 >= pb.sqp_max_iter) status = 2;
         }

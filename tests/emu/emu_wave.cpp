@@ -42,6 +42,7 @@ struct EmuWave {
         swapcontext(&g_s->ctx[lane_], &g_s->ctx[(lane_ + 1) % WAVE]);
     }
     void sync_lockstep() { sync(); }
+    double rcp(double x) { return 1.0 / x; }
     double readlane(double v, int src)
     {
         g_s->tmp[lane_] = v;
@@ -70,12 +71,12 @@ struct EmuWave {
         sync();
         return t[lane_];
     }
-    double min(double v)
+    double max(double v)
     {
         g_s->tmp[lane_] = v;
         sync();
         double r = g_s->tmp[0];
-        for (int l = 1; l < WAVE; ++l) r = g_s->tmp[l] < r ? g_s->tmp[l] : r;
+        for (int l = 1; l < WAVE; ++l) r = g_s->tmp[l] > r ? g_s->tmp[l] : r;
         sync();
         return r;
     }

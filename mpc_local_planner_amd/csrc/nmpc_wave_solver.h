@@ -531,11 +531,14 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     mu_aff = w.sum(ma) / mcount;
                     const double sr = mu_aff / mu;
                     smu = sr * sr * sr * mu;
+                    // Mehrotra's second-order term, damped when the affine step is almost fully
+                    // blocked (undamped it over-corrects and the iteration can cycle)
+                    const double csc = fmin(1.0, 4.0 * a_aff);
                     double dG[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        ctl[q] = smu - dtl[q] * dll[q];
-                        ctu[q] = smu - dtu[q] * dlu[q];
+                        ctl[q] = smu - csc * dtl[q] * dll[q];
+                        ctu[q] = smu - csc * dtu[q] * dlu[q];
                         dG[q] = mq[q] ? (-ctl[q] * itl[q] + ctu[q] * itu[q]) : 0.0;
                     }
                     if (act) {

@@ -78,7 +78,10 @@ def config4(B, start=0, seed=SEED, vref=5.0):
     close to their bounds so that constraints are active."""
     i = np.arange(start, start + B, dtype=np.uint64)
     sgn = lambda d: np.where(uniform01(seed, i, d) < 0.5, -1.0, 1.0)
-    psi0 = uniform(seed, i, 0, -1.2, 0.2)
+    # psi0 range narrowed w.r.t. config 2 so that the path heading psi0 - epsi0 stays inside
+    # (-1.3, 0.9): the reference's front-end never hands the solver a near-vertical cubic
+    # (it picks the frame rotation with the best fit, PathTrackingSys.cpp:63-79)
+    psi0 = uniform(seed, i, 0, -0.6, 0.2)
     v = uniform(seed, i, 1, 0.0, 2.0)
     delta = sgn(11) * uniform(seed, i, 2, 0.45, 0.57)
     thr = uniform(seed, i, 3, 0.8, 1.0)

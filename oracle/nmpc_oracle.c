@@ -375,12 +375,15 @@ int orc_qp_ipm(const orc_config *cfg, const orc_qp *qp, double *dx, double *du, 
         mu_aff /= (double)m;
         const double sr = mu_aff / mu;
         const double smu = sr * sr * sr * mu; /* sigma * mu */
+        /* second-order (Mehrotra) term damped when the affine step is almost fully blocked:
+           an undamped correction then over-corrects and the iteration can cycle */
+        const double csc = fmin(1.0, 4.0 * a_aff);
         /* corrector: only the bounded components of the gradient change */
         memset(dG, 0, sizeof(double) * (size_t)N * 8);
         for (int k = 0; k < N; ++k)
             for (int j = 0; j < NB; ++j) {
                 const size_t q = (size_t)k * NB + j;
-                const double cl = smu - dtl[q] * dll[q], cu = smu - dtu[q] * dlu[q];
+                const double cl = smu - csc * dtl[q] * dll[q], cu = smu - csc * dtu[q] * dlu[q];
                 dG[k * NZ + BIDX[j]] = msk[q] * (-cl / tl[q] + cu / tu[q]);
             }
         riccati_solve(qp, &w, Hd, dG, rb, 0, dzc);
@@ -391,7 +394,7 @@ int orc_qp_ipm(const orc_config *cfg, const orc_qp *qp, double *dx, double *du, 
             for (int j = 0; j < NB; ++j) {
                 const size_t q = (size_t)k * NB + j;
                 const double dw = dz[k * NZ + BIDX[j]];
-                const double cl = smu - dtl[q] * dll[q], cu = smu - dtu[q] * dlu[q];
+                const double cl = smu - csc * dtl[q] * dll[q], cu = smu - csc * dtu[q] * dlu[q];
                 const double ntl = msk[q] * (dw + rtl[q]), ntu = msk[q] * (-dw + rtu[q]);
                 dll[q] = msk[q] * (cl / tl[q] - ll[q] - ll[q] / tl[q] * ntl);
                 dlu[q] = msk[q] * (cu / tu[q] - lu[q] - lu[q] / tu[q] * ntu);

@@ -71,9 +71,7 @@ def cpu_baseline(N, seconds_target=12.0):
     from oracle import oracle as orc
     from mpc_local_planner_amd import capi, scenarios as sc
     c = capi.default_config(N, 0.35)
-    ocfg = orc.default_config(N, 0.35, ipm_mu0=c.ipm_mu0, ipm_thr0=c.ipm_thr0, ipm_tau=c.ipm_tau,
-                              ipm_tol_mu=c.ipm_tol_mu, ipm_tol_lin=c.ipm_tol_lin,
-                              ipm_max_iter=c.ipm_max_iter)
+    ocfg = orc.config_like(c)
     x0, p = sc.config2(64)
     t = time.perf_counter()
     orc.rti_batch(ocfg, x0, p)

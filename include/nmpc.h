@@ -45,6 +45,7 @@ typedef struct nmpc_config {
     /* interior-point QP solver (replaces the HPIPM options of mpcPathTracking.py:123-127) */
     int ipm_max_iter;
     double ipm_mu0, ipm_thr0, ipm_tau, ipm_tol_mu, ipm_tol_lin;
+    double ipm_tol_comp;  /* every slack/multiplier pair: min(t_i, lam_i) <= this at termination */
 } nmpc_config;
 
 typedef struct nmpc_handle nmpc_handle;
@@ -84,6 +85,10 @@ int nmpc_set_bounds(nmpc_handle *h, const double *bnd, int B);
  * mask[i] != 0 (all if mask == NULL) start their next solve from x_k = x0, u_k = 0.
  * Instances whose last solve failed are reset automatically, as the reference does. */
 int nmpc_reset(nmpc_handle *h, const uint8_t *mask, int B);
+
+/* Replaces the ocp_nlp_out_set "x"/"u" loop of Solver::setInitGuess (src/AcadosSolver.cpp:86-91)
+ * with an arbitrary iterate: x[B][N+1][6], u[B][N][2].  The instances become "warm". */
+int nmpc_set_iterate(nmpc_handle *h, const double *x, const double *u, int B);
 
 /* Replaces path_tracking_acados_solve (src/AcadosPathTracking.cpp:26) for instances 0..B-1:
  * NMPC_MODE_RTI = one SQP-RTI iteration (rti_phase 0, src/AcadosSolver.cpp:42-48);

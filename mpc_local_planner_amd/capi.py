@@ -22,12 +22,14 @@ class Config(C.Structure):
         ("lbx", C.c_double * 2), ("ubx", C.c_double * 2),
         ("ipm_max_iter", C.c_int), ("ipm_mu0", C.c_double), ("ipm_thr0", C.c_double),
         ("ipm_tau", C.c_double), ("ipm_tol_mu", C.c_double), ("ipm_tol_lin", C.c_double),
+        ("ipm_tol_comp", C.c_double),
     ]
 
 
 EXPORTS = [
     "nmpc_default_config", "nmpc_create", "nmpc_destroy", "nmpc_set_x0", "nmpc_set_params",
-    "nmpc_set_inputs_device", "nmpc_set_weights", "nmpc_set_bounds", "nmpc_reset", "nmpc_solve",
+    "nmpc_set_inputs_device", "nmpc_set_weights", "nmpc_set_bounds", "nmpc_reset", "nmpc_set_iterate",
+    "nmpc_solve",
     "nmpc_sync", "nmpc_get", "nmpc_get_controls", "nmpc_device_ptr", "nmpc_stream",
     "nmpc_capacity", "nmpc_horizon", "nmpc_last_error",
 ]
@@ -59,6 +61,7 @@ def lib():
     l.nmpc_set_weights.argtypes = [vp, dp, C.c_int]
     l.nmpc_set_bounds.argtypes = [vp, dp, C.c_int]
     l.nmpc_reset.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int]
+    l.nmpc_set_iterate.argtypes = [vp, dp, dp, C.c_int]
     l.nmpc_solve.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double]
     l.nmpc_sync.argtypes = [vp]
     l.nmpc_get.argtypes = [vp, C.c_int, dp, dp, ip, dp, ip, ip]
@@ -157,6 +160,12 @@ class BatchSolver:
             mask = np.ascontiguousarray(mask, dtype=np.uint8)
             check(lib().nmpc_reset(self._h, mask.ctypes.data_as(C.POINTER(C.c_uint8)), mask.shape[0]),
                   "nmpc_reset")
+
+    def set_iterate(self, x, u):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, self.N + 1, 6)
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(-1, self.N, 2)
+        assert x.shape[0] == u.shape[0]
+        check(lib().nmpc_set_iterate(self._h, _dp(x), _dp(u), x.shape[0]), "nmpc_set_iterate")
 
     def solve(self, B=None, mode=MODE_RTI, max_iter=1, tol=1e-6):
         check(lib().nmpc_solve(self._h, B or self.capacity, mode, max_iter, tol), "nmpc_solve")

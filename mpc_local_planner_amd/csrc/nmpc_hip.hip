@@ -153,6 +153,7 @@ int nmpc_default_config(nmpc_config *c, int N, double dt)
     c->ipm_tau = 0.995;
     c->ipm_tol_mu = 1e-10;
     c->ipm_tol_lin = 1e-10;
+    c->ipm_tol_comp = 1e-11;
     return NMPC_OK;
 }
 
@@ -304,6 +305,26 @@ int nmpc_reset(nmpc_handle *h, const uint8_t *mask, int B)
     return NMPC_OK;
 }
 
+int nmpc_set_iterate(nmpc_handle *h, const double *x, const double *u, int B)
+{
+    if (!h || !x || !u || B <= 0 || B > h->capacity) return NMPC_EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t N = (size_t)h->cfg.N, N1 = N + 1;
+    h->h_traj.resize((size_t)B * N1 * 8);
+    double *t = h->h_traj.data();
+    for (size_t b = 0; b < (size_t)B; ++b)
+        for (size_t k = 0; k < N1; ++k) {
+            double *r = t + (b * N1 + k) * 8;
+            memcpy(r, x + (b * N1 + k) * 6, sizeof(double) * 6);
+            r[6] = k < N ? u[(b * N + k) * 2] : 0.0;
+            r[7] = k < N ? u[(b * N + k) * 2 + 1] : 0.0;
+        }
+    HIP_TRY(hipMemcpyAsync(h->d_traj, t, sizeof(double) * h->h_traj.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_reset, 0, (size_t)B, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return NMPC_OK;
+}
+
 int nmpc_solve(nmpc_handle *h, int B, int mode, int max_iter, double tol)
 {
     if (!h || B <= 0 || B > h->capacity) return NMPC_EINVAL;
@@ -320,6 +341,7 @@ int nmpc_solve(nmpc_handle *h, int B, int mode, int max_iter, double tol)
     a.pb.tau = h->cfg.ipm_tau;
     a.pb.tol_mu = h->cfg.ipm_tol_mu;
     a.pb.tol_lin = h->cfg.ipm_tol_lin;
+    a.pb.tol_comp = h->cfg.ipm_tol_comp;
     a.pb.sqp_max_iter = (mode == NMPC_MODE_RTI) ? 1 : max_iter;
     a.pb.sqp_tol = tol;
     a.B = B;

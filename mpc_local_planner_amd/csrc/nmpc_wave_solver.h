@@ -37,7 +37,7 @@ struct Problem {            // uniform over the launch
     double dt;              // shooting interval
     double inv_wheelbase;   // 1/L
     int ipm_max_iter;
-    double mu0, thr0, tau, tol_mu, tol_lin;
+    double mu0, thr0, tau, tol_mu, tol_lin, tol_comp;
     int sqp_max_iter;       // 1 = SQP-RTI (one QP per call)
     double sqp_tol;
 };
@@ -324,12 +324,17 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
         w.sync();   // BA columns visible
         for (;; ++it) {
             // ---- E-A: barrier system of this node
-            double mu_loc = 0.0;
+            double mu_loc = 0.0, c_loc = 0.0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) mu_loc += tl[q] * ll[q] + tu[q] * lu[q];
+            for (int q = 0; q < 4; ++q) {
+                mu_loc += tl[q] * ll[q] + tu[q] * lu[q];
+                // pairwise complementarity (masked pairs hold t = 1, lambda = 0)
+                c_loc = fmax(c_loc, fmax(fmin(tl[q], ll[q]), fmin(tu[q], lu[q])));
+            }
             const double mu = w.sum(mu_loc) / mcount;
+            const double cmax = w.max(c_loc);
             if (!(mu == mu)) { qp_status = 1; break; }
-            if (it > 0 && mu <= pb.tol_mu && lin_scale <= pb.tol_lin) { qp_status = 0; break; }
+            if (it > 0 && mu <= pb.tol_mu && lin_scale <= pb.tol_lin && cmax <= pb.tol_comp) { qp_status = 0; break; }
             if (it >= pb.ipm_max_iter) { qp_status = (mu <= 1e-8 && lin_scale <= 1e-8) ? 0 : 4; break; }
 
             double G[8];

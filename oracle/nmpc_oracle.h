@@ -47,6 +47,7 @@ typedef struct orc_config {
     double ipm_tau;
     double ipm_tol_mu;
     double ipm_tol_lin;
+    double ipm_tol_comp; /* max_i min(t_i, lam_i): pairwise complementarity, see orc_qp_ipm */
 } orc_config;
 
 /* fills cfg with the reference's defaults (N and dt given explicitly) */

@@ -24,6 +24,7 @@ class Config(C.Structure):
         ("lbx", C.c_double * 2), ("ubx", C.c_double * 2),
         ("ipm_max_iter", C.c_int), ("ipm_mu0", C.c_double), ("ipm_thr0", C.c_double),
         ("ipm_tau", C.c_double), ("ipm_tol_mu", C.c_double), ("ipm_tol_lin", C.c_double),
+        ("ipm_tol_comp", C.c_double),
     ]
 
 
@@ -104,6 +105,23 @@ def default_config(N=40, dt=0.35, **over):
                 cur[i] = e
         else:
             setattr(cfg, k, v)
+    return cfg
+
+
+def config_like(c):
+    """Oracle config with every same-named field copied from another config struct (e.g. the
+    HIP library's nmpc_config), so that both sides walk the same iteration sequence."""
+    cfg = Config()
+    names = {n for n, _ in c._fields_}
+    for n, _ in Config._fields_:
+        if n not in names:
+            raise KeyError(n)
+        v = getattr(c, n)
+        if hasattr(v, "__len__"):
+            for i, e in enumerate(v):
+                getattr(cfg, n)[i] = e
+        else:
+            setattr(cfg, n, v)
     return cfg
 
 

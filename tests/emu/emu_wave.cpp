@@ -95,7 +95,7 @@ void lane_main(int lane)
 }  // namespace
 
 extern "C" int emu_solve_batch(int N, double dt, double wheelbase, int ipm_max_iter, double mu0,
-                               double thr0, double tau, double tol_mu, double tol_lin,
+                               double thr0, double tau, double tol_mu, double tol_lin, double tol_comp,
                                int sqp_max_iter, double sqp_tol, int B, const double *x0,
                                const double *p, const double *W, const double *bnd, double *traj,
                                double *ctrl, int *status, int *iters, int *sqp_iters, double *cost,
@@ -104,7 +104,7 @@ extern "C" int emu_solve_batch(int N, double dt, double wheelbase, int ipm_max_i
     nmpcw::Problem pb;
     pb.N = N; pb.dt = dt; pb.inv_wheelbase = 1.0 / wheelbase;
     pb.ipm_max_iter = ipm_max_iter; pb.mu0 = mu0; pb.thr0 = thr0; pb.tau = tau;
-    pb.tol_mu = tol_mu; pb.tol_lin = tol_lin; pb.sqp_max_iter = sqp_max_iter; pb.sqp_tol = sqp_tol;
+    pb.tol_mu = tol_mu; pb.tol_lin = tol_lin; pb.tol_comp = tol_comp; pb.sqp_max_iter = sqp_max_iter; pb.sqp_tol = sqp_tol;
     Sched s;
     g_s = &s;
     s.stacks.resize(STACK * WAVE);

@@ -1,0 +1,56 @@
+"""ctypes binding of the CPU lane emulator (tests/emu/): runs the kernel body
+mpc_local_planner_amd/csrc/nmpc_wave_solver.h on 64 emulated lanes.  Test infrastructure."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "emu", "libnmpc_emu.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = [os.path.join(_HERE, "emu", "emu_wave.cpp"),
+               os.path.join(_HERE, "..", "mpc_local_planner_amd", "csrc", "nmpc_wave_solver.h")]
+        if not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src):
+            subprocess.check_call(["make", "-C", os.path.join(_HERE, "emu"), "-s", "-B"])
+        _lib = C.CDLL(_LIB)
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+        d, i = C.c_double, C.c_int
+        _lib.emu_solve_batch.argtypes = [i, d, d, i, d, d, d, d, d, d, i, d, i,
+                                         dp, dp, dp, dp, dp, dp, ip, ip, ip, dp, i]
+    return _lib
+
+
+def solve_batch(cfg, x0, p, W=None, bnd=None, traj=None, cold=True, sqp_max_iter=1, sqp_tol=1e-6):
+    """cfg: any config struct with the nmpc_config field names.  Returns dict like BatchSolver.get."""
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    B, N = x0.shape[0], cfg.N
+    if W is None:
+        W = np.tile(np.array(cfg.W[:]), (B, 1))
+    if bnd is None:
+        bnd = np.tile(np.array([cfg.lbu[0], cfg.lbu[1], cfg.lbx[0], cfg.lbx[1],
+                                cfg.ubu[0], cfg.ubu[1], cfg.ubx[0], cfg.ubx[1]]), (B, 1))
+    W = np.ascontiguousarray(W, dtype=np.float64)
+    bnd = np.ascontiguousarray(bnd, dtype=np.float64)
+    if traj is None:
+        traj = np.zeros((B, N + 1, 8))
+    ctrl = np.zeros((B, 6))
+    st = np.zeros(B, dtype=np.int32)
+    it = np.zeros(B, dtype=np.int32)
+    sq = np.zeros(B, dtype=np.int32)
+    cost = np.zeros(B)
+    d = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    rc = lib().emu_solve_batch(N, cfg.dt, cfg.wheelbase, cfg.ipm_max_iter, cfg.ipm_mu0, cfg.ipm_thr0,
+                               cfg.ipm_tau, cfg.ipm_tol_mu, cfg.ipm_tol_lin, cfg.ipm_tol_comp,
+                               sqp_max_iter, sqp_tol, B, d(x0), d(p), d(W), d(bnd), d(traj), d(ctrl),
+                               i(st), i(it), i(sq), d(cost), 1 if cold else 0)
+    assert rc == 0, "emulated lanes diverged in their sync count"
+    return dict(x=traj[:, :, :6].copy(), u=traj[:, :N, 6:].copy(), traj=traj, ctrl=ctrl, status=st,
+                ipm_iters=it, sqp_iters=sq, cost=cost)

@@ -1,0 +1,76 @@
+"""The kernel body (mpc_local_planner_amd/csrc/nmpc_wave_solver.h), run on the CPU lane emulator
+(tests/emu/), against the oracle: checks lane mappings, the LDS layout and the exchange protocol
+on a machine without a GPU.  The GPU itself is checked in tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import emu_binding as emu
+from mpc_local_planner_amd import scenarios as sc
+from oracle import oracle as orc
+
+TOL = 1e-9
+
+
+def _err(g, xo, uo):
+    B = xo.shape[0]
+    return np.maximum(np.abs(g["x"] - xo).reshape(B, -1).max(1), np.abs(g["u"] - uo).reshape(B, -1).max(1))
+
+
+@pytest.mark.parametrize("N,gen", [(40, sc.config2), (10, sc.config2), (63, sc.config2), (1, sc.config2),
+                                   (2, sc.config2), (40, sc.config4)])
+def test_emulated_wave_matches_oracle_cold_and_warm(N, gen):
+    B = 12
+    cfg = orc.default_config(N, 0.35)
+    x0, p = gen(B)
+    g = emu.solve_batch(cfg, x0, p)
+    xo, uo, so, io = orc.rti_batch(cfg, x0, p)
+    assert (g["status"] == so).all() and (so == 0).all()
+    assert (np.abs(g["ipm_iters"] - io) <= 1).all()
+    scale = max(1.0, np.abs(xo).max())
+    assert _err(g, xo, uo).max() <= 1e-6 * scale
+    assert np.median(_err(g, xo, uo)) <= TOL * scale
+    # control record layout (include/nmpc.h: nmpc_get_controls)
+    assert np.array_equal(g["ctrl"][:, 0:2], g["u"][:, 0, :])
+    if N >= 2:
+        assert np.array_equal(g["ctrl"][:, 2:4], g["x"][:, 1, 4:6])
+    # warm call from the oracle's iterate (no shift)
+    traj = np.zeros((B, N + 1, 8)); traj[:, :, :6] = xo; traj[:, :N, 6:] = uo
+    g2 = emu.solve_batch(cfg, x0, p, traj=traj, cold=False)
+    xo2, uo2, so2, _ = orc.rti_batch(cfg, x0, p, xo.copy(), uo.copy(), cold=False)
+    ok = so2 == 0
+    assert (g2["status"][ok] == 0).all()
+    assert _err(g2, xo2, uo2)[ok].max() <= 1e-6 * max(1.0, np.abs(xo2).max())
+
+
+def test_emulated_wave_per_instance_weights_and_bounds():
+    N, B = 20, 6
+    cfg = orc.default_config(N, 0.35)
+    x0, p = sc.config2(B)
+    rng = np.random.default_rng(3)
+    W = np.array(cfg.W[:])[None, :] * rng.uniform(0.5, 2.0, size=(B, 7))
+    bnd = np.tile(np.array([-80, -0.33, -0.57, -1.0, 80, 0.33, 0.57, 1.0]), (B, 1))
+    bnd[:, 1] *= rng.uniform(0.5, 1.5, size=B); bnd[:, 5] = -bnd[:, 1]
+    g = emu.solve_batch(cfg, x0, p, W=W, bnd=bnd)
+    for i in range(B):
+        oc = orc.default_config(N, 0.35)
+        for m in range(7):
+            oc.W[m] = W[i, m]
+        oc.lbu[1], oc.ubu[1] = bnd[i, 1], bnd[i, 5]
+        xo, uo = orc.init_guess(oc, x0[i])
+        st = orc.rti(oc, x0[i], p[i], xo, uo)
+        assert st.status == 0 and g["status"][i] == 0
+        assert np.abs(g["x"][i] - xo).max() <= 1e-7 and np.abs(g["u"][i] - uo).max() <= 1e-7
+        assert abs(g["cost"][i] - st.cost) <= 1e-9 * max(1.0, abs(st.cost))
+
+
+def test_emulated_wave_sqp_mode_converges_to_the_oracle_fixed_point():
+    N, B = 30, 4
+    cfg = orc.default_config(N, 0.35)
+    x0, p = sc.config2(B)
+    g = emu.solve_batch(cfg, x0, p, sqp_max_iter=30, sqp_tol=1e-9)
+    for i in range(B):
+        xo, uo = orc.init_guess(cfg, x0[i])
+        st = orc.sqp(cfg, x0[i], p[i], xo, uo, 40, 1e-9)
+        assert st.status == 0 and g["status"][i] == 0
+        assert np.abs(g["x"][i] - xo).max() <= 1e-6 and np.abs(g["u"][i] - uo).max() <= 1e-6
+        assert g["sqp_iters"][i] >= 2

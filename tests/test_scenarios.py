@@ -1,0 +1,23 @@
+"""Counter-based scenario generator: shards are independent of how the batch is split."""
+import numpy as np
+
+from mpc_local_planner_amd import scenarios as sc
+
+
+def test_shards_concatenate_to_the_global_batch():
+    x, p = sc.config2(64)
+    xa, pa = sc.config2(24, start=0)
+    xb, pb = sc.config2(40, start=24)
+    assert np.array_equal(np.vstack([xa, xb]), x) and np.array_equal(np.vstack([pa, pb]), p)
+
+
+def test_distributions_follow_survey_8d():
+    x, p = sc.config2(4096)
+    assert (x[:, 0] == 0).all() and (x[:, 1] == 0).all()
+    assert x[:, 2].min() >= -1.2 and x[:, 2].max() <= 0.2
+    assert x[:, 3].min() >= 0 and x[:, 3].max() <= 8
+    assert np.abs(x[:, 4]).max() <= 0.3 and x[:, 5].min() >= -0.5 and x[:, 5].max() <= 0.8
+    assert np.abs(p[:, 4]).max() <= 0.05 and (p[:, 5] == 5.0).all()
+    assert abs(p[:, 0].std() - 0.5) < 0.05
+    x4, p4 = sc.config4(1024)
+    assert (np.abs(x4[:, 4]) >= 0.45).all() and (x4[:, 5] >= 0.8).all() and (np.abs(p4[:, 0]) >= 2.0).all()

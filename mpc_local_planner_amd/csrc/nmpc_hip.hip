@@ -21,10 +21,13 @@ struct GpuWave {
     double *lds_;
     __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }
     __device__ __forceinline__ double *lds() { return lds_; }
+    // value the optimiser must treat as unknown: keeps per-sweep address set-up inside the
+    // interior-point loop instead of hoisted into ~45 live registers
+    __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
     // exchange through LDS between lanes of the single wave of this workgroup
     __device__ __forceinline__ void sync() { __syncthreads(); }
     // ordering that lock-step execution of one wave already provides
-    __device__ __forceinline__ void sync_lockstep() {}
+    __device__ __forceinline__ void sync_lockstep() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
     __device__ __forceinline__ double readlane(double v, int src)
     {
         const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);

@@ -11,17 +11,23 @@
 //   -> path_tracking_acados_solve (SQP-RTI)  src/AcadosPathTracking.cpp:26  [acados/HPIPM, not in tree]
 //   model / cost / bounds                    acados/mpcPathTracking.py:41-47, 63-80, 100-115
 //
-// Work mapping inside the wave
-//   * "stage layout": lane k owns shooting node k (x_k,u_k, slacks, multipliers).  Linearisation
-//     (ERK4 + forward sensitivities, Gauss-Newton cost), all interior-point element-wise work and
-//     step-length reductions run here, 40 of 64 lanes busy at N=40, no LDS traffic.
-//   * "entry layout": lane (i,j) = (lane>>3, lane&7) owns entry (i,j) of the 8x8 stage matrices
-//     in [u0,u1,X,Y,psi,v,delta,thr] order.  The Riccati factorisation sweep runs here, serial
-//     in the stage index, three LDS exchanges per stage.
-//   * the three vector-only sweeps per interior-point iteration run wave-uniform (every lane
-//     carries the same 6-vector) straight from LDS broadcasts.
-//   Per-stage matrices (dynamics Jacobian rows X,Y,psi; Riccati gains) live in LDS; rows v,delta,thr
-//   of [B A] are compile/launch-time constants of this model and stay in registers.
+// Work mapping inside the wave (z ordering [u0,u1,X,Y,psi,v,delta,thr], augmented index 8 = "1")
+//   * stage layout: lane k owns shooting node k (x_k,u_k, slacks, multipliers).  Linearisation
+//     (ERK4 + forward sensitivities, Gauss-Newton cost) and all element-wise interior-point
+//     work run here; wave-wide sums/maxima give the step lengths.
+//   * factor sweep (serial in k): the Riccati recursion on the AUGMENTED matrices
+//       Pt = [P p; p' .] (7x7),  BAt = [B A b] (6x9),  Ht = [H g; g' .] (9x9)
+//     so that the gradient/gap vectors ride along as the 9th column.  Three phases per stage,
+//     each a 6-7 term dot product per lane, exchanged through LDS:
+//       phase 1  lane (m,j), 54 lanes : Mt[m][j] = Pt[m][:] . BAt[:][j]
+//       phase 2  lane (i<=j), 44 lanes: Ht[i][j] = cost + BAt[:][i] . Mt[:][j]
+//       phase 3  same lanes, i >= 2   : Schur complement on the 2x2 input block -> Pt, K, kff
+//     Every lane addresses LDS through pointers set up once per sweep (stride 0 for constant
+//     columns), so the loop body has no branches and no index arithmetic.
+//   * vector sweeps (corrector backward, both forward passes): lane c = lane & 7 owns one row /
+//     column, the recursion vector is replicated and re-gathered through LDS once per stage.
+//   Rows v,delta,thr of [B A] are constants of this model (a33, a35, b31, h) and columns X,Y are
+//   unit vectors: they live in a small constant table, not per stage.
 #pragma once
 
 #ifndef NMPC_DEV
@@ -56,24 +62,26 @@ struct InstanceIO {
     int cold;               // != 0: start from x_k = x0, u_k = 0 (AcadosSolver.cpp:78-92)
 };
 
-// LDS layout, in doubles
-constexpr int BA_STRIDE = 32;   // 8 columns x (3 variable rows + pad)
-constexpr int SLOT = 28;
-constexpr int S_K = 0;          // K[2][6]            (also: in  gam[4],Q00,Q01,Q02,0 | G[8])
-constexpr int S_KFF = 12;       // kff[2]
-constexpr int S_INV = 14;       // inv00,inv01,inv11
-constexpr int S_D = 18;         // r_b[6] -> dz_aff[8] -> dG[4] -> dz_cor[8]
-constexpr int S_TAB = 0;        // input view
-constexpr int S_G = 8;
-constexpr int X_P = 0, X_PV = 36, X_M = 44, X_V = 92, X_H = 100, X_XN = 120, X_SIZE = 128;
-constexpr int lds_doubles(int N) { return N * (BA_STRIDE + SLOT) + X_SIZE; }
-
-struct Lin {        // per-node linearisation kept in stage-layout registers
-    double Q00, Q01, Q02;   // variable entries of the GN Hessian (X,X) (X,Y) (X,psi)
-    double g[8];            // gradient [u0,u1,X,Y,psi,v,delta,thr]
-    double rb[6];           // dynamics gap phi(x_k,u_k) - x_{k+1}
-};
-
+// ---- LDS layout, in doubles.  [pseudo-stage -1 | stage 0 .. N-1 | exchange area]
+constexpr int ST = 44;          // per stage
+constexpr int O_BA = 0;         // [c][3]: columns u0,u1,psi,v,delta,thr x rows X,Y,psi of [B A]
+constexpr int O_KP = 18;        // (K0[c],K1[c]) c = X..thr, then (kff0,kff1)
+constexpr int O_INV = 32;       // i00,i01,i11,0
+constexpr int O_D = 36;         // slot k: rb_k[6] -> z_{k+1}[8] = du,dx (forward sweeps) -> dG_k[4]
+constexpr int O_TAB = 18;       // input view of the factor sweep: gam[4],Q00,Q01,Q02,(unused)
+constexpr int O_G = 26;         //   G[8]
+// pseudo-stage -1 holds the constant tables in [0,36) and z_0 in its O_D
+constexpr int C_BOT = 0;        // [c][3]: rows v,delta,thr of the six variable columns
+constexpr int C_UNIT = 18;      // (1,0,0),(0,1,0): rows X,Y,psi of columns X,Y
+constexpr int C_ZERO = 24;      // 0,0,0,0
+// exchange area after the stages
+constexpr int X_P = 0;          // Pt rows [6][8]: P[m][0..5], p[m], pad
+constexpr int X_M = 48;         // Mt col-major [9][6]
+constexpr int X_HU = 104;       // (Ht[0][j], Ht[1][j]) j = 0..8
+constexpr int X_V = 124;        // recursion vector of the backward sweep, double-buffered [2][6]
+constexpr int X_DUM = 136;      // dummy target for lanes with nothing to store
+constexpr int X_SIZE = 140;
+constexpr int lds_doubles(int N) { return (N + 1) * ST + X_SIZE; }
 
 // sin/cos/tan for the bounded angles of this model (|x| < ~1e5): two-constant Cody-Waite
 // reduction with fma and the classic degree-13/14 minimax kernels (errors < 1 ulp on the
@@ -102,7 +110,6 @@ NMPC_DEV void sincos_bounded(double x, double *sn, double *cs)
 // ERK4 step with forward sensitivities of the kinematic bicycle, structure exploited:
 //   rows delta,thr of phi are exact integrators, columns X,Y of d(phi)/dx are unit vectors,
 //   the v-row is a constant-coefficient linear ODE.  sens columns: psi,v,delta,thr,u0,u1.
-template <class W>
 NMPC_DEV void rk4_sens(const Problem &pb, const double *x, const double *u, double gp,
                        double *phi, double *aX, double *aY, double *aP, double *aV)
 {
@@ -162,157 +169,134 @@ NMPC_DEV void rk4_sens(const Problem &pb, const double *x, const double *u, doub
     aV[0] = 0.0;      aV[1] = 1.0 + h6 * sVv; aV[2] = 0.0; aV[3] = h6 * sVt; aV[4] = 0.0;     aV[5] = h6 * sV1;
 }
 
+// entry of an 8-vector in z ordering that belongs to bounded variable q (u0,u1,delta,thr)
+#define NMPC_ZQ(a, q) ((q) == 0 ? (a)[0] : (q) == 1 ? (a)[1] : (q) == 2 ? (a)[6] : (a)[7])
+// variable-column index of z index j (u0,u1,-,-,psi,v,delta,thr) -> 0,1,-,-,2,3,4,5
+#define NMPC_VCOL(j) ((j) < 2 ? (j) : (j) - 2)
+
 template <class W>
 NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
 {
     const int lane = w.lane();
     const int N = pb.N;
     const double h = pb.dt;
-    double *lds = w.lds();
-    double *ldsBA = lds;
-    double *ldsSlot = lds + N * BA_STRIDE;
-    double *ldsX = lds + N * (BA_STRIDE + SLOT);
-
-    // ---------------------------------------------------------------- instance data (uniform)
-    double x0[6], par[6], Wt[7], lb[4], ub[4];
-#pragma unroll
-    for (int m = 0; m < 6; ++m) { x0[m] = io.x0[m]; par[m] = io.p[m]; }
-#pragma unroll
-    for (int m = 0; m < 7; ++m) Wt[m] = io.W[m];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) { lb[m] = io.bnd[m]; ub[m] = io.bnd[4 + m]; }
-    double gp, gpc;
-    sincos_bounded(par[4], &gp, &gpc);
-    gp *= 9.81;
+    double *const ct = w.lds();                 // pseudo-stage -1 (constant tables, z_0)
+    double *const stg = ct + ST;                // stage k at stg + k*ST
+    double *const xa = ct + (N + 1) * ST;       // exchange area
 
     // ---------------------------------------------------------------- iterate (stage layout)
     const bool has_node = lane <= N;       // lanes 0..N hold x_k
     const bool act = lane < N;             // lanes 0..N-1 hold u_k and a shooting interval
+    const bool actx = act && lane >= 1;    // state bounds exist on nodes 1..N-1 only
     const int node = has_node ? lane : N;
     double xb[6], ub_[2];                   // NLP iterate of this node
     {
         const double *t = io.traj + node * 8;
 #pragma unroll
-        for (int m = 0; m < 6; ++m) xb[m] = io.cold ? x0[m] : t[m];
+        for (int m = 0; m < 6; ++m) xb[m] = io.cold ? io.x0[m] : t[m];
         ub_[0] = (io.cold || !act) ? 0.0 : t[6];
         ub_[1] = (io.cold || !act) ? 0.0 : t[7];
     }
-    const bool actx = act && lane >= 1;    // state bounds exist on nodes 1..N-1 only
-    const bool mq[4] = {act, act, actx, actx};
     const double mcount = (double)(4 * N + 4 * (N - 1));
+    double lb[4], ub[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { lb[q] = io.bnd[q]; ub[q] = io.bnd[4 + q]; }
+    const double R00 = h * io.W[5], R11 = h * io.W[6], Q11 = h * io.W[0], Q22 = h * io.W[1],
+                 Q33 = h * io.W[2], Q44 = h * io.W[3], Q55 = h * io.W[4];
 
-    // entry-layout constants
-    const int ei = lane >> 3, ej = lane & 7;
+    double *const last = stg + (N - 1) * ST;   // the backward sweeps start at stage N-1
+
     int total_ipm = 0, status = 0, sqp_it = 0;
     double cost_out = 0.0;
-    bool bot_ready = false;
-    double cjb[3] = {0, 0, 0}, cib[3] = {0, 0, 0};   // rows v,delta,thr of columns ej / ei of [B A]
-    double a33 = 0, a35 = 0, b31 = 0;
-
-    // constant part of the stage Hessian seen by entry (ei,ej) and where its variable part sits
-    double hconst = 0.0;
-    int htab = 7;
-    if (ei == ej) {
-        if (ei == 0) { hconst = h * Wt[5]; htab = 0; }
-        if (ei == 1) { hconst = h * Wt[6]; htab = 1; }
-        if (ei == 2) { htab = 4; }
-        if (ei == 3) hconst = h * Wt[0];
-        if (ei == 4) hconst = h * Wt[1];
-        if (ei == 5) hconst = h * Wt[2];
-        if (ei == 6) { hconst = h * Wt[3]; htab = 2; }
-        if (ei == 7) { hconst = h * Wt[4]; htab = 3; }
-    } else if ((ei == 2 && ej == 3) || (ei == 3 && ej == 2)) {
-        htab = 5;
-    } else if ((ei == 2 && ej == 4) || (ei == 4 && ej == 2)) {
-        htab = 6;
-    }
-    const int prow = (ei >= 2) ? (ei - 2) : (ej < 6 ? ej : 5);   // row of P this lane multiplies with
+    bool tables_ready = false;
+    double a33 = 0.0, a35 = 0.0, b31 = 0.0;   // constant entries of [B A] (row v)
 
     for (sqp_it = 0; sqp_it < pb.sqp_max_iter; ++sqp_it) {
         // ------------------------------------------------------------ linearise (stage layout)
-        Lin L;
-        double dx0[6];
-#pragma unroll
-        for (int m = 0; m < 6; ++m) dx0[m] = x0[m] - w.readlane(xb[m], 0);
+        double rb[6], g[8], Q00, Q01, Q02;
         {
+            double gp, gpc;
+            sincos_bounded(io.p[4], &gp, &gpc);
+            gp *= 9.81;
             double phi[6], aX[6], aY[6], aP[6], aV[6];
-            rk4_sens<W>(pb, xb, ub_, gp, phi, aX, aY, aP, aV);
-            // x_{k+1} from the next lane
+            rk4_sens(pb, xb, ub_, gp, phi, aX, aY, aP, aV);
 #pragma unroll
             for (int m = 0; m < 6; ++m) {
-                const double xn = w.shfl_down1(xb[m]);
-                L.rb[m] = act ? (phi[m] - xn) : 0.0;
+                const double xn = w.shfl_down1(xb[m]);       // x_{k+1} from the next lane
+                rb[m] = act ? (phi[m] - xn) : 0.0;
             }
-            if (lane == 0) {   // fold the known dx_0 into the first gap: b_0 += A_0 dx0
-                L.rb[0] += dx0[0] + aX[0] * dx0[2] + aX[1] * dx0[3] + aX[2] * dx0[4] + aX[3] * dx0[5];
-                L.rb[1] += dx0[1] + aY[0] * dx0[2] + aY[1] * dx0[3] + aY[2] * dx0[4] + aY[3] * dx0[5];
-                L.rb[2] += aP[0] * dx0[2] + aP[1] * dx0[3] + aP[2] * dx0[4] + aP[3] * dx0[5];
-                L.rb[3] += aV[1] * dx0[3] + aV[3] * dx0[5];
-                L.rb[4] += dx0[4];
-                L.rb[5] += dx0[5];
-            }
-            // variable rows X,Y,psi of [B A] -> LDS, column-major, column order u0,u1,X,Y,psi,v,delta,thr
-            if (act) {
-                double *c = ldsBA + lane * BA_STRIDE;
-                c[0] = aX[4];  c[1] = aY[4];  c[2] = aP[4];  c[3] = 0.0;   // u0
-                c[4] = aX[5];  c[5] = aY[5];  c[6] = aP[5];  c[7] = 0.0;   // u1
-                c[8] = 1.0;    c[9] = 0.0;    c[10] = 0.0;   c[11] = 0.0;  // X
-                c[12] = 0.0;   c[13] = 1.0;   c[14] = 0.0;   c[15] = 0.0;  // Y
-                c[16] = aX[0]; c[17] = aY[0]; c[18] = aP[0]; c[19] = 0.0;  // psi
-                c[20] = aX[1]; c[21] = aY[1]; c[22] = aP[1]; c[23] = 0.0;  // v
-                c[24] = aX[2]; c[25] = aY[2]; c[26] = aP[2]; c[27] = 0.0;  // delta
-                c[28] = aX[3]; c[29] = aY[3]; c[30] = aP[3]; c[31] = 0.0;  // thr
-            }
-            if (!bot_ready) {   // constant rows (v,delta,thr) of [B A]: identical on every lane
-                a33 = w.readlane(aV[1], 0);
-                a35 = w.readlane(aV[3], 0);
-                b31 = w.readlane(aV[5], 0);
-                const double bot[8][3] = {{0, h, 0}, {b31, 0, h}, {0, 0, 0}, {0, 0, 0},
-                                          {0, 0, 0}, {a33, 0, 0}, {0, 1, 0}, {a35, 0, 1}};
+            if (lane == 0) {   // fold the known dx_0 = x0 - x_0 into the first gap: b_0 += A_0 dx0
+                double d[6];
 #pragma unroll
-                for (int c = 0; c < 8; ++c)
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        if (ej == c) cjb[r] = bot[c][r];
-                        if (ei == c) cib[r] = bot[c][r];
-                    }
-                bot_ready = true;
+                for (int m = 0; m < 6; ++m) d[m] = io.x0[m] - xb[m];
+                rb[0] += d[0] + aX[0] * d[2] + aX[1] * d[3] + aX[2] * d[4] + aX[3] * d[5];
+                rb[1] += d[1] + aY[0] * d[2] + aY[1] * d[3] + aY[2] * d[4] + aY[3] * d[5];
+                rb[2] += aP[0] * d[2] + aP[1] * d[3] + aP[2] * d[4] + aP[3] * d[5];
+                rb[3] += aV[1] * d[3] + aV[3] * d[5];
+                rb[4] += d[4];
+                rb[5] += d[5];
+            }
+            if (act) {   // variable rows X,Y,psi of [B A], column-major, columns u0,u1,psi,v,delta,thr
+                double *c = stg + lane * ST + O_BA;
+                c[0] = aX[4];  c[1] = aY[4];  c[2] = aP[4];
+                c[3] = aX[5];  c[4] = aY[5];  c[5] = aP[5];
+                c[6] = aX[0];  c[7] = aY[0];  c[8] = aP[0];
+                c[9] = aX[1];  c[10] = aY[1]; c[11] = aP[1];
+                c[12] = aX[2]; c[13] = aY[2]; c[14] = aP[2];
+                c[15] = aX[3]; c[16] = aY[3]; c[17] = aP[3];
+            }
+            if (!tables_ready) {   // constant rows (v,delta,thr) of [B A]: identical on every lane
+                a33 = w.readlane(aV[1], 0); a35 = w.readlane(aV[3], 0); b31 = w.readlane(aV[5], 0);
+                if (lane == 0) {
+                    double *c = ct + C_BOT;
+                    c[0] = 0.0;  c[1] = h;    c[2] = 0.0;     // u0
+                    c[3] = b31;  c[4] = 0.0;  c[5] = h;       // u1
+                    c[6] = 0.0;  c[7] = 0.0;  c[8] = 0.0;     // psi
+                    c[9] = a33;  c[10] = 0.0; c[11] = 0.0;    // v
+                    c[12] = 0.0; c[13] = 1.0; c[14] = 0.0;    // delta
+                    c[15] = a35; c[16] = 0.0; c[17] = 1.0;    // thr
+                    double *u = ct + C_UNIT;
+                    u[0] = 1.0; u[1] = 0.0; u[2] = 0.0; u[3] = 0.0; u[4] = 1.0; u[5] = 0.0;
+                    double *zz = ct + C_ZERO;
+                    zz[0] = 0.0; zz[1] = 0.0; zz[2] = 0.0; zz[3] = 0.0;
+                }
+                tables_ready = true;
             }
             // Gauss-Newton cost terms (mpcPathTracking.py:63-80,103)
+            const double c0 = io.p[0], c1 = io.p[1], c2 = io.p[2], c3 = io.p[3];
             const double X = xb[0];
-            const double s = 3.0 * par[3] * X * X + 2.0 * par[2] * X + par[1];
-            const double dsl = 6.0 * par[3] * X + 2.0 * par[2];
-            const double ypath = par[3] * X * X * X + par[2] * X * X + par[1] * X + par[0];
+            const double s = 3.0 * c3 * X * X + 2.0 * c2 * X + c1;
+            const double dsl = 6.0 * c3 * X + 2.0 * c2;
+            const double ypath = c3 * X * X * X + c2 * X * X + c1 * X + c0;
             const double cte = ypath - xb[1];
             const double epsi = xb[2] - atan(s);
             const double d = -dsl / (1.0 + s * s);
-            const double ev = xb[3] - par[5];
-            L.Q00 = h * (Wt[0] * s * s + Wt[1] * d * d);
-            L.Q01 = -h * Wt[0] * s;
-            L.Q02 = h * Wt[1] * d;
-            L.g[0] = h * Wt[5] * ub_[0];
-            L.g[1] = h * Wt[6] * ub_[1];
-            L.g[2] = h * (Wt[0] * s * cte + Wt[1] * d * epsi);
-            L.g[3] = -h * Wt[0] * cte;
-            L.g[4] = h * Wt[1] * epsi;
-            L.g[5] = h * Wt[2] * ev;
-            L.g[6] = h * Wt[3] * xb[4];
-            L.g[7] = h * Wt[4] * xb[5];
-            const double cst = 0.5 * h * (Wt[0] * cte * cte + Wt[1] * epsi * epsi + Wt[2] * ev * ev +
-                                          Wt[3] * xb[4] * xb[4] + Wt[4] * xb[5] * xb[5] +
-                                          Wt[5] * ub_[0] * ub_[0] + Wt[6] * ub_[1] * ub_[1]);
+            const double ev = xb[3] - io.p[5];
+            Q00 = Q11 * s * s + Q22 * d * d;
+            Q01 = -Q11 * s;
+            Q02 = Q22 * d;
+            g[0] = R00 * ub_[0];
+            g[1] = R11 * ub_[1];
+            g[2] = Q11 * s * cte + Q22 * d * epsi;
+            g[3] = -Q11 * cte;
+            g[4] = Q22 * epsi;
+            g[5] = Q33 * ev;
+            g[6] = Q44 * xb[4];
+            g[7] = Q55 * xb[5];
+            const double cst = 0.5 * (Q11 * cte * cte + Q22 * epsi * epsi + Q33 * ev * ev +
+                                      Q44 * xb[4] * xb[4] + Q55 * xb[5] * xb[5] +
+                                      R00 * ub_[0] * ub_[0] + R11 * ub_[1] * ub_[1]);
             cost_out = w.sum(act ? cst : 0.0);
         }
-        const double R00 = h * Wt[5], R11 = h * Wt[6], Q11 = h * Wt[0], Q22 = h * Wt[1],
-                     Q33 = h * Wt[2], Q44 = h * Wt[3], Q55 = h * Wt[4];
 
         // ------------------------------------------------------------ interior point (stage layout)
         // bounded variables of this node: u0,u1,delta,thr -> z index 0,1,6,7
+        const double cur[4] = {ub_[0], ub_[1], xb[4], xb[5]};
+        const bool mq[4] = {act, act, actx, actx};
         double tl[4], tu[4], ll[4], lu[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const double cur = (q == 0) ? ub_[0] : (q == 1) ? ub_[1] : (q == 2) ? xb[4] : xb[5];
-            const double a = fmax(cur - lb[q], pb.thr0), b = fmax(ub[q] - cur, pb.thr0);
+            const double a = fmax(cur[q] - lb[q], pb.thr0), b = fmax(ub[q] - cur[q], pb.thr0);
             tl[q] = mq[q] ? a : 1.0;
             tu[q] = mq[q] ? b : 1.0;
             ll[q] = mq[q] ? pb.mu0 * w.rcp(a) : 0.0;
@@ -321,7 +305,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
         double z[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // QP iterate of this node [du0,du1,dX..dthr]
         double lin_scale = 1.0;
         int it = 0, qp_status = 4;
-        w.sync();   // BA columns visible
+        w.sync();   // BA columns and constant tables visible
         for (;; ++it) {
             // ---- E-A: barrier system of this node
             double mu_loc = 0.0, c_loc = 0.0;
@@ -336,191 +320,263 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
             if (!(mu == mu)) { qp_status = 1; break; }
             if (it > 0 && mu <= pb.tol_mu && lin_scale <= pb.tol_lin && cmax <= pb.tol_comp) { qp_status = 0; break; }
             if (it >= pb.ipm_max_iter) { qp_status = (mu <= 1e-8 && lin_scale <= 1e-8) ? 0 : 4; break; }
-
-            double G[8];
-            G[0] = R00 * z[0] + L.g[0];
-            G[1] = R11 * z[1] + L.g[1];
-            G[2] = L.Q00 * z[2] + L.Q01 * z[3] + L.Q02 * z[4] + L.g[2];
-            G[3] = L.Q01 * z[2] + Q11 * z[3] + L.g[3];
-            G[4] = L.Q02 * z[2] + Q22 * z[4] + L.g[4];
-            G[5] = Q33 * z[5] + L.g[5];
-            G[6] = Q44 * z[6] + L.g[6];
-            G[7] = Q55 * z[7] + L.g[7];
-            double gam[4];
+            {
+                double G[8];
+                G[0] = R00 * z[0] + g[0];
+                G[1] = R11 * z[1] + g[1];
+                G[2] = Q00 * z[2] + Q01 * z[3] + Q02 * z[4] + g[2];
+                G[3] = Q01 * z[2] + Q11 * z[3] + g[3];
+                G[4] = Q02 * z[2] + Q22 * z[4] + g[4];
+                G[5] = Q33 * z[5] + g[5];
+                G[6] = Q44 * z[6] + g[6];
+                G[7] = Q55 * z[7] + g[7];
+                double gam[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double cur = (q == 0) ? ub_[0] : (q == 1) ? ub_[1] : (q == 2) ? xb[4] : xb[5];
-                const double wv = (q == 0) ? z[0] : (q == 1) ? z[1] : (q == 2) ? z[6] : z[7];
-                const double rtl = mq[q] ? (wv - (lb[q] - cur) - tl[q]) : 0.0;
-                const double rtu = mq[q] ? ((ub[q] - cur) - wv - tu[q]) : 0.0;
-                const double rl = ll[q] * w.rcp(tl[q]), ru = lu[q] * w.rcp(tu[q]);
-                gam[q] = rl + ru;
-                const double gq = rl * rtl - ru * rtu;
-                if (q == 0) G[0] += gq;
-                if (q == 1) G[1] += gq;
-                if (q == 2) G[6] += gq;
-                if (q == 3) G[7] += gq;
-            }
-            if (act) {
-                double *sl = ldsSlot + lane * SLOT;
-                sl[S_TAB + 0] = gam[0]; sl[S_TAB + 1] = gam[1]; sl[S_TAB + 2] = gam[2]; sl[S_TAB + 3] = gam[3];
-                sl[S_TAB + 4] = L.Q00;  sl[S_TAB + 5] = L.Q01;  sl[S_TAB + 6] = L.Q02;  sl[S_TAB + 7] = 0.0;
+                for (int q = 0; q < 4; ++q) {
+                    const double wv = NMPC_ZQ(z, q);
+                    const double rtl = mq[q] ? (wv - (lb[q] - cur[q]) - tl[q]) : 0.0;
+                    const double rtu = mq[q] ? ((ub[q] - cur[q]) - wv - tu[q]) : 0.0;
+                    const double rl = ll[q] * w.rcp(tl[q]), ru = lu[q] * w.rcp(tu[q]);
+                    gam[q] = rl + ru;
+                    const double gq = rl * rtl - ru * rtu;
+                    if (q == 0) G[0] += gq;
+                    if (q == 1) G[1] += gq;
+                    if (q == 2) G[6] += gq;
+                    if (q == 3) G[7] += gq;
+                }
+                if (act) {
+                    double *sl = stg + lane * ST;
+                    sl[O_TAB + 0] = gam[0]; sl[O_TAB + 1] = gam[1]; sl[O_TAB + 2] = gam[2]; sl[O_TAB + 3] = gam[3];
+                    sl[O_TAB + 4] = Q00;    sl[O_TAB + 5] = Q01;    sl[O_TAB + 6] = Q02;
 #pragma unroll
-                for (int m = 0; m < 8; ++m) sl[S_G + m] = G[m];
+                    for (int m = 0; m < 8; ++m) sl[O_G + m] = G[m];
 #pragma unroll
-                for (int m = 0; m < 6; ++m) sl[S_D + m] = L.rb[m];
+                    for (int m = 0; m < 6; ++m) sl[O_D + m] = rb[m];
+                }
             }
             // terminal cost-to-go: none (no *_e cost or bound in mpcPathTracking.py)
-            if (lane < 36) ldsX[X_P + lane] = 0.0;
-            if (lane < 8) ldsX[X_PV + lane] = 0.0;
+            if (lane < 48) xa[X_P + lane] = 0.0;
             w.sync();
 
-            // ---- sweep B: Riccati factorisation, entry layout, k = N-1 .. 0
+            // ---- factor sweep, k = N-1 .. 0 (augmented Riccati recursion)
+            {
+                // per-lane LDS pointers of this sweep, recomputed here (a few dozen integer ops per
+                // interior-point iteration) instead of living in ~45 registers through the whole solve;
+                // strides are in doubles per stage: ST for per-stage data, 0 for constants
+                const int fl = w.opaque(lane);
+                // factor phase 1: fl (m,j) = (fl/9, fl%9), fls >= 54 idle (dummy store)
+                const int f1m = fl < 54 ? fl / 9 : 5, f1j = fl < 54 ? fl % 9 : 8;
+                // factor phases 2,3: triangular map fl -> (i <= j), i in 0..7, j in 0..8; fls >= 44 idle
+                int f2i = 7, f2j = 8;
+                {
+                    const int start[9] = {0, 9, 17, 24, 30, 35, 39, 42, 44};
+            #pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (fl >= start[i] && fl < start[i + 1]) { f2i = i; f2j = i + (fl - start[i]); }
+                }
+                const bool f2on = fl < 44;
+                // column j of BAt for phase 1 (top = rows X,Y,psi, bot = rows v,delta,thr)
+                const double *pTopJ, *pBotJ;
+                int sTopJ, sBotJ;
+                if (f1j == 8) { pTopJ = last + O_D; pBotJ = last + O_D + 3; sTopJ = ST; sBotJ = ST; }
+                else if (f1j == 2 || f1j == 3) { pTopJ = ct + C_UNIT + 3 * (f1j - 2); pBotJ = ct + C_ZERO; sTopJ = 0; sBotJ = 0; }
+                else { pTopJ = last + O_BA + 3 * NMPC_VCOL(f1j); pBotJ = ct + C_BOT + 3 * NMPC_VCOL(f1j); sTopJ = ST; sBotJ = 0; }
+                // column i of BAt for phase 2 (i < 8)
+                const double *pTopI, *pBotI;
+                int sTopI;
+                if (f2i == 2 || f2i == 3) { pTopI = ct + C_UNIT + 3 * (f2i - 2); pBotI = ct + C_ZERO; sTopI = 0; }
+                else { pTopI = last + O_BA + 3 * NMPC_VCOL(f2i); pBotI = ct + C_BOT + 3 * NMPC_VCOL(f2i); sTopI = ST; }
+                const double e8 = (f1j == 8) ? 1.0 : 0.0;
+                const double *const pProw = xa + X_P + f1m * 8;
+                double *const pMw = fl < 54 ? xa + X_M + f1j * 6 + f1m : xa + X_DUM;
+                const double *const pMr = xa + X_M + f2j * 6;
+                // cost part of Ht[i][j]: a constant plus (at most) one per-stage table entry
+                double hconst = 0.0;
+                const double *pTab = ct + C_ZERO;
+                int sTab = 0;
+                {
+                    int off = -1;
+                    if (f2j == 8) off = (O_G - O_TAB) + f2i;                 // gradient column
+                    else if (f2i == f2j) {
+                        if (f2i == 0) { hconst = R00; off = 0; }
+                        if (f2i == 1) { hconst = R11; off = 1; }
+                        if (f2i == 2) off = 4;
+                        if (f2i == 3) hconst = Q11;
+                        if (f2i == 4) hconst = Q22;
+                        if (f2i == 5) hconst = Q33;
+                        if (f2i == 6) { hconst = Q44; off = 2; }
+                        if (f2i == 7) { hconst = Q55; off = 3; }
+                    } else if (f2i == 2 && f2j == 3) off = 5;
+                    else if (f2i == 2 && f2j == 4) off = 6;
+                    if (off >= 0) { pTab = last + O_TAB + off; sTab = ST; }
+                }
+                // phase 2 stores of the two input rows, phase 3 loads/stores
+                double *pHw1 = xa + X_DUM, *pHw2 = xa + X_DUM;
+                if (f2on && f2i < 2) pHw1 = xa + X_HU + 2 * f2j + f2i;
+                if (f2on && f2i == 0 && f2j == 1) pHw2 = xa + X_HU + 1;      // Ht[1][0] = Ht[0][1]
+                const double *const pHj = xa + X_HU + 2 * f2j;
+                const double *const pHi = xa + X_HU + 2 * f2i;
+                double *pPw1 = xa + X_DUM, *pPw2 = xa + X_DUM, *pKw = xa + X_DUM, *pIw = xa + X_DUM;
+                int sKw = 0, sIw = 0;
+                if (f2on && f2i >= 2) {
+                    pPw1 = xa + X_P + (f2i - 2) * 8 + (f2j - 2);
+                    if (f2j <= 7) pPw2 = xa + X_P + (f2j - 2) * 8 + (f2i - 2);
+                    if (f2i == 2) { pKw = last + O_KP + 2 * (f2j - 2); sKw = ST; }
+                    if (f2i == 2 && f2j == 2) { pIw = last + O_INV; sIw = ST; }
+                }
+                const double *tj = pTopJ, *bj = pBotJ, *ti = pTopI, *tb = pTab;
+                double *kw = pKw, *iw = pIw;
 #pragma unroll 1
-            for (int k = N - 1; k >= 0; --k) {
-                const double *ba = ldsBA + k * BA_STRIDE;
-                double *sl = ldsSlot + k * SLOT;
-                double cj[6], ci[6], pr[6], rbk[6];
-#pragma unroll
-                for (int m = 0; m < 3; ++m) { cj[m] = ba[ej * 4 + m]; ci[m] = ba[ei * 4 + m]; }
-#pragma unroll
-                for (int m = 0; m < 3; ++m) { cj[3 + m] = cjb[m]; ci[3 + m] = cib[m]; }
-#pragma unroll
-                for (int m = 0; m < 6; ++m) { pr[m] = ldsX[X_P + prow * 6 + m]; rbk[m] = sl[S_D + m]; }
-                const double hc = hconst + sl[S_TAB + htab];
-                const double Gj = sl[S_G + ej];
-                double Mv = 0.0, vv = ldsX[X_PV + prow];
-#pragma unroll
-                for (int m = 0; m < 6; ++m) { Mv += pr[m] * cj[m]; vv += pr[m] * rbk[m]; }
-                if (ei >= 2) ldsX[X_M + ej * 6 + (ei - 2)] = Mv;        // M = P [B A], stored by column
-                if (ei == 0 && ej < 6) ldsX[X_V + ej] = vv;             // v = P r_b + p
-                w.sync();
-                double Hv = hc, hj = Gj;
-#pragma unroll
-                for (int m = 0; m < 6; ++m) {
-                    Hv += ci[m] * ldsX[X_M + ej * 6 + m];               // H = Hcost + [B A]' M
-                    hj += cj[m] * ldsX[X_V + m];                        // h = G + [B A]' v
+                for (int k = N - 1; k >= 0; --k) {
+                    // phase 1: Mt[m][j] = Pt[m][0..5] . BAt[0..5][j] + p[m] [j == 8]
+                    double acc = pProw[6] * e8;
+                    acc = fma(pProw[0], tj[0], acc);
+                    acc = fma(pProw[1], tj[1], acc);
+                    acc = fma(pProw[2], tj[2], acc);
+                    acc = fma(pProw[3], bj[0], acc);
+                    acc = fma(pProw[4], bj[1], acc);
+                    acc = fma(pProw[5], bj[2], acc);
+                    *pMw = acc;
+                    w.sync();
+                    // phase 2: Ht[i][j] = cost[i][j] + BAt[0..5][i] . Mt[0..5][j]
+                    double Hv = hconst + *tb;
+                    Hv = fma(ti[0], pMr[0], Hv);
+                    Hv = fma(ti[1], pMr[1], Hv);
+                    Hv = fma(ti[2], pMr[2], Hv);
+                    Hv = fma(pBotI[0], pMr[3], Hv);
+                    Hv = fma(pBotI[1], pMr[4], Hv);
+                    Hv = fma(pBotI[2], pMr[5], Hv);
+                    *pHw1 = Hv;
+                    *pHw2 = Hv;
+                    w.sync();
+                    // phase 3: eliminate the inputs
+                    const double H00 = xa[X_HU + 0], H01 = xa[X_HU + 1], H11 = xa[X_HU + 3];
+                    const double H0j = pHj[0], H1j = pHj[1], H0i = pHi[0], H1i = pHi[1];
+                    const double rdet = w.rcp(H00 * H11 - H01 * H01);
+                    const double i00 = H11 * rdet, i01 = -H01 * rdet, i11 = H00 * rdet;
+                    const double K0 = -(i00 * H0j + i01 * H1j), K1 = -(i01 * H0j + i11 * H1j);
+                    const double Pn = Hv + H0i * K0 + H1i * K1;
+                    *pPw1 = Pn;
+                    *pPw2 = Pn;
+                    kw[0] = K0; kw[1] = K1;
+                    iw[0] = i00; iw[1] = i01; iw[2] = i11;
+                    w.sync();
+                    tj -= sTopJ; bj -= sBotJ; ti -= sTopI; tb -= sTab; kw -= sKw; iw -= sIw;
                 }
-                if (ei < 2) ldsX[X_H + ej * 2 + ei] = Hv;               // rows u0,u1 of H
-                const double H00 = w.readlane(Hv, 0), H01 = w.readlane(Hv, 1), H11 = w.readlane(Hv, 9);
-                const double h0 = w.readlane(hj, 0), h1 = w.readlane(hj, 1);
-                const double rdet = w.rcp(H00 * H11 - H01 * H01);
-                const double i00 = H11 * rdet, i01 = -H01 * rdet, i11 = H00 * rdet;
-                w.sync();
-                const double Hj0 = ldsX[X_H + ej * 2], Hj1 = ldsX[X_H + ej * 2 + 1];
-                const double Hi0 = ldsX[X_H + ei * 2], Hi1 = ldsX[X_H + ei * 2 + 1];
-                const double K0 = -(i00 * Hj0 + i01 * Hj1), K1 = -(i01 * Hj0 + i11 * Hj1);
-                const double Pn = Hv + Hi0 * K0 + Hi1 * K1;
-                const double pn = hj + K0 * h0 + K1 * h1;
-                if (ei >= 2 && ej >= ei) {                              // upper triangle, mirrored
-                    ldsX[X_P + (ei - 2) * 6 + (ej - 2)] = Pn;
-                    ldsX[X_P + (ej - 2) * 6 + (ei - 2)] = Pn;
-                }
-                if (ei == 2 && ej >= 2) ldsX[X_PV + (ej - 2)] = pn;
-                if (ei < 2 && ej >= 2) sl[S_K + ei * 6 + (ej - 2)] = (ei == 0) ? K0 : K1;
-                if (lane == 0) {
-                    sl[S_KFF + 0] = -(i00 * h0 + i01 * h1);
-                    sl[S_KFF + 1] = -(i01 * h0 + i11 * h1);
-                    sl[S_INV + 0] = i00; sl[S_INV + 1] = i01; sl[S_INV + 2] = i11;
-                }
-                w.sync();
             }
 
-            // ---- sweeps F1 / Bv / F2: wave-uniform vector recursions
-            double dzs[8];       // affine step of this node (stage layout)
-            double ctl[4], ctu[4], smu = 0.0, mu_aff = 0.0;
+            // ---- pass 0: forward sweep with the affine right-hand side, then the corrector
+            //      pass 1: backward + forward sweep of the corrector increment (homogeneous dynamics)
+            double dzs[8];        // affine step of this node
+            double smu = 0.0, csc = 0.0, mu_aff = 0.0;
 #pragma unroll 1
             for (int pass = 0; pass < 2; ++pass) {
                 if (pass == 1) {
-                    // backward vector sweep with the corrector right-hand side
+                    // backward vector sweep: lane component vc, p replicated
                     double p6[6] = {0, 0, 0, 0, 0, 0};
+                    const int vl = w.opaque(lane) & 7;
+                    const double *tv;                // column vl, rows X,Y,psi
+                    int sTopV;
+                    if (vl == 2 || vl == 3) { tv = ct + C_UNIT + 3 * (vl - 2); sTopV = 0; }
+                    else { tv = last + O_BA + 3 * NMPC_VCOL(vl); sTopV = ST; }
+                    const double *dg = ct + C_ZERO;   // corrector gradient entry of component vl
+                    int sDgV = 0;
+                    if (vl < 2) { dg = last + O_D + vl; sDgV = ST; }
+                    if (vl >= 6) { dg = last + O_D + vl - 4; sDgV = ST; }
+                    const double *kp = last + O_KP + 2 * (vl >= 2 ? vl - 2 : 0);
+                    // rows v,delta,thr of column vl
+                    const double cb0 = vl == 1 ? b31 : vl == 5 ? a33 : vl == 7 ? a35 : 0.0;
+                    const double cb1 = vl == 0 ? h : vl == 6 ? 1.0 : 0.0;
+                    const double cb2 = vl == 1 ? h : vl == 7 ? 1.0 : 0.0;
+                    double *sl = last;
 #pragma unroll 1
                     for (int k = N - 1; k >= 0; --k) {
-                        const double *ba = ldsBA + k * BA_STRIDE;
-                        double *sl = ldsSlot + k * SLOT;
-                        const double dg0 = sl[S_D + 0], dg1 = sl[S_D + 1], dg2 = sl[S_D + 2], dg3 = sl[S_D + 3];
-                        const double hu0 = dg0 + ba[0] * p6[0] + ba[1] * p6[1] + ba[2] * p6[2] + h * p6[4];
-                        const double hu1 = dg1 + ba[4] * p6[0] + ba[5] * p6[1] + ba[6] * p6[2] + b31 * p6[3] + h * p6[5];
-                        double hx[6];
-                        hx[0] = p6[0];
-                        hx[1] = p6[1];
-                        hx[2] = p6[2] + ba[16] * p6[0] + ba[17] * p6[1];
-                        hx[3] = a33 * p6[3] + ba[20] * p6[0] + ba[21] * p6[1] + ba[22] * p6[2];
-                        hx[4] = dg2 + p6[4] + ba[24] * p6[0] + ba[25] * p6[1] + ba[26] * p6[2];
-                        hx[5] = dg3 + p6[5] + ba[28] * p6[0] + ba[29] * p6[1] + ba[30] * p6[2] + a35 * p6[3];
-                        const double i00 = sl[S_INV + 0], i01 = sl[S_INV + 1], i11 = sl[S_INV + 2];
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) p6[c] = hx[c] + sl[S_K + c] * hu0 + sl[S_K + 6 + c] * hu1;
+                        double hc = *dg;
+                        hc = fma(tv[0], p6[0], hc);
+                        hc = fma(tv[1], p6[1], hc);
+                        hc = fma(tv[2], p6[2], hc);
+                        hc = fma(cb0, p6[3], hc);
+                        hc = fma(cb1, p6[4], hc);
+                        hc = fma(cb2, p6[5], hc);
+                        const double hu0 = w.readlane(hc, 0), hu1 = w.readlane(hc, 1);
+                        const double pn = hc + kp[0] * hu0 + kp[1] * hu1;
+                        double *xv = xa + X_V + (k & 1) * 6;
+                        if (vl >= 2) xv[vl - 2] = pn;
+                        const double i00 = sl[O_INV + 0], i01 = sl[O_INV + 1], i11 = sl[O_INV + 2];
                         if (lane == 0) {
-                            sl[S_KFF + 0] = -(i00 * hu0 + i01 * hu1);
-                            sl[S_KFF + 1] = -(i01 * hu0 + i11 * hu1);
+                            sl[O_KP + 12] = -(i00 * hu0 + i01 * hu1);
+                            sl[O_KP + 13] = -(i01 * hu0 + i11 * hu1);
                         }
+                        w.sync();
+#pragma unroll
+                        for (int m = 0; m < 6; ++m) p6[m] = xv[m];
+                        tv -= sTopV; dg -= sDgV; kp -= ST; sl -= ST;
+                    }
+                }
+                // forward sweep: du uniform, lane row vr of dx+, z_k stored in slot k-1
+                {
+                    const double rbs = pass == 0 ? 1.0 : 0.0;
+                    double dx[6] = {0, 0, 0, 0, 0, 0};
+                    const int vl = w.opaque(lane) & 7;
+                    const int vr = vl < 6 ? vl : 5;     // row vr of [B A] (lanes 6,7 duplicate row 5)
+                    const double *rw = vr < 3 ? stg + O_BA + vr : ct + C_BOT + (vr - 3);
+                    const int sRowV = vr < 3 ? ST : 0;
+                    const double eX = vr == 0 ? 1.0 : 0.0, eY = vr == 1 ? 1.0 : 0.0;
+                    double *sl = stg;
+#pragma unroll 1
+                    for (int k = 0; k < N; ++k) {
+                        double du0 = sl[O_KP + 12], du1 = sl[O_KP + 13];
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) {
+                            du0 = fma(sl[O_KP + 2 * c], dx[c], du0);
+                            du1 = fma(sl[O_KP + 2 * c + 1], dx[c], du1);
+                        }
+                        double dn = rbs * sl[O_D + vr];
+                        dn = fma(eX, dx[0], dn);
+                        dn = fma(eY, dx[1], dn);
+                        dn = fma(rw[0], du0, dn);
+                        dn = fma(rw[3], du1, dn);
+                        dn = fma(rw[6], dx[2], dn);
+                        dn = fma(rw[9], dx[3], dn);
+                        dn = fma(rw[12], dx[4], dn);
+                        dn = fma(rw[15], dx[5], dn);
+                        w.sync_lockstep();          // every lane has read r_b of this slot
+                        sl[O_D + 2 + vr] = dn;      // dx_{k+1}
+                        if (lane == 0) { sl[O_D - ST] = du0; sl[O_D - ST + 1] = du1; }   // du_k, beside dx_k
+                        w.sync();
+#pragma unroll
+                        for (int m = 0; m < 6; ++m) dx[m] = sl[O_D + 2 + m];
+                        rw += sRowV; sl += ST;
+                    }
+                    if (lane == 0) {                // z_0 = (du_0, 0): dx_0 is folded into r_b
+#pragma unroll
+                        for (int m = 0; m < 6; ++m) ct[O_D + 2 + m] = 0.0;
                     }
                     w.sync();
                 }
-                // forward sweep
-                double dx[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll 1
-                for (int k = 0; k < N; ++k) {
-                    const double *ba = ldsBA + k * BA_STRIDE;
-                    double *sl = ldsSlot + k * SLOT;
-                    double rbk[6];
-#pragma unroll
-                    for (int m = 0; m < 6; ++m) rbk[m] = (pass == 0) ? sl[S_D + m] : 0.0;
-                    double du0 = sl[S_KFF + 0], du1 = sl[S_KFF + 1];
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) { du0 += sl[S_K + c] * dx[c]; du1 += sl[S_K + 6 + c] * dx[c]; }
-                    double dn[6];
-                    dn[0] = rbk[0] + dx[0] + ba[16] * dx[2] + ba[20] * dx[3] + ba[24] * dx[4] + ba[28] * dx[5] + ba[0] * du0 + ba[4] * du1;
-                    dn[1] = rbk[1] + dx[1] + ba[17] * dx[2] + ba[21] * dx[3] + ba[25] * dx[4] + ba[29] * dx[5] + ba[1] * du0 + ba[5] * du1;
-                    dn[2] = rbk[2] + dx[2] + ba[22] * dx[3] + ba[26] * dx[4] + ba[30] * dx[5] + ba[2] * du0 + ba[6] * du1;
-                    dn[3] = rbk[3] + a33 * dx[3] + a35 * dx[5] + b31 * du1;
-                    dn[4] = rbk[4] + dx[4] + h * du0;
-                    dn[5] = rbk[5] + dx[5] + h * du1;
-                    w.sync_lockstep();   // every lane has read r_b of this slot (free on a real wave)
-                    if (lane == 0) {
-                        sl[S_D + 0] = du0; sl[S_D + 1] = du1;
-#pragma unroll
-                        for (int m = 0; m < 6; ++m) sl[S_D + 2 + m] = dx[m];
-                    }
-#pragma unroll
-                    for (int m = 0; m < 6; ++m) dx[m] = dn[m];
-                }
-                if (lane == 0) {
-                    ldsX[X_XN + 0] = 0.0; ldsX[X_XN + 1] = 0.0;
-#pragma unroll
-                    for (int m = 0; m < 6; ++m) ldsX[X_XN + 2 + m] = dx[m];
-                }
-                w.sync();
-                // ---- stage layout: pick up the direction of this node
+                // ---- stage layout: pick up the direction of this node (slot node-1 holds z_node)
                 double dzl[8];
                 {
-                    const double *src = act ? (ldsSlot + lane * SLOT + S_D) : (ldsX + X_XN);
+                    const double *src = ct + node * ST + O_D;
 #pragma unroll
                     for (int m = 0; m < 8; ++m) dzl[m] = has_node ? src[m] : 0.0;
-                }
-                // residuals and ratios of this node at the current (unchanged) iterate
-                double rtl[4], rtu[4], itl[4], itu[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const double cur = (q == 0) ? ub_[0] : (q == 1) ? ub_[1] : (q == 2) ? xb[4] : xb[5];
-                    const double wv = (q == 0) ? z[0] : (q == 1) ? z[1] : (q == 2) ? z[6] : z[7];
-                    rtl[q] = mq[q] ? (wv - (lb[q] - cur) - tl[q]) : 0.0;
-                    rtu[q] = mq[q] ? ((ub[q] - cur) - wv - tu[q]) : 0.0;
-                    itl[q] = w.rcp(tl[q]);
-                    itu[q] = w.rcp(tu[q]);
+                    if (!act) { dzl[0] = 0.0; dzl[1] = 0.0; }
                 }
                 if (pass == 0) {
                     // E-B: affine step lengths, centring parameter, corrector right-hand side
 #pragma unroll
                     for (int m = 0; m < 8; ++m) dzs[m] = dzl[m];
                     double r_loc = 0.0;
-                    double dtl[4], dtu[4], dll[4], dlu[4];
+                    double dtl[4], dtu[4], dll[4], dlu[4], itl[4], itu[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const double dw = (q == 0) ? dzl[0] : (q == 1) ? dzl[1] : (q == 2) ? dzl[6] : dzl[7];
-                        dtl[q] = mq[q] ? (dw + rtl[q]) : 0.0;
-                        dtu[q] = mq[q] ? (-dw + rtu[q]) : 0.0;
+                        const double wv = NMPC_ZQ(z, q), dw = NMPC_ZQ(dzl, q);
+                        const double rtl = mq[q] ? (wv - (lb[q] - cur[q]) - tl[q]) : 0.0;
+                        const double rtu = mq[q] ? ((ub[q] - cur[q]) - wv - tu[q]) : 0.0;
+                        itl[q] = w.rcp(tl[q]);
+                        itu[q] = w.rcp(tu[q]);
+                        dtl[q] = mq[q] ? (dw + rtl) : 0.0;
+                        dtu[q] = mq[q] ? (-dw + rtu) : 0.0;
                         dll[q] = -ll[q] - ll[q] * itl[q] * dtl[q];
                         dlu[q] = -lu[q] - lu[q] * itu[q] * dtu[q];
                         // largest -d/v over the positive variables (step to the boundary = 1/that)
@@ -538,48 +594,51 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     smu = sr * sr * sr * mu;
                     // Mehrotra's second-order term, damped when the affine step is almost fully
                     // blocked (undamped it over-corrects and the iteration can cycle)
-                    const double csc = fmin(1.0, 4.0 * a_aff);
-                    double dG[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        ctl[q] = smu - csc * dtl[q] * dll[q];
-                        ctu[q] = smu - csc * dtu[q] * dlu[q];
-                        dG[q] = mq[q] ? (-ctl[q] * itl[q] + ctu[q] * itu[q]) : 0.0;
-                    }
+                    csc = fmin(1.0, 4.0 * a_aff);
+                    // (the pick-up reads above are ordered before these stores by the reductions)
                     if (act) {
-                        double *sl = ldsSlot + lane * SLOT;
+                        double *sl = stg + lane * ST + O_D;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) sl[S_D + q] = dG[q];
+                        for (int q = 0; q < 4; ++q) {
+                            const double ctl = smu - csc * dtl[q] * dll[q], ctu = smu - csc * dtu[q] * dlu[q];
+                            sl[q] = mq[q] ? (-ctl * itl[q] + ctu * itu[q]) : 0.0;
+                        }
                     }
                     w.sync();
                 } else {
                     // E-C: combined direction, step length, update
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) dzs[m] += dzl[m];
                     double r_loc = 0.0;
                     double dtl[4], dtu[4], dll[4], dlu[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const double dw = (q == 0) ? dzs[0] : (q == 1) ? dzs[1] : (q == 2) ? dzs[6] : dzs[7];
-                        dtl[q] = mq[q] ? (dw + rtl[q]) : 0.0;
-                        dtu[q] = mq[q] ? (-dw + rtu[q]) : 0.0;
-                        dll[q] = mq[q] ? (ctl[q] * itl[q] - ll[q] - ll[q] * itl[q] * dtl[q]) : 0.0;
-                        dlu[q] = mq[q] ? (ctu[q] * itu[q] - lu[q] - lu[q] * itu[q] * dtu[q]) : 0.0;
-                        r_loc = fmax(r_loc, fmax(-dtl[q] * itl[q], -dtu[q] * itu[q]));
+                        const double wv = NMPC_ZQ(z, q), dwa = NMPC_ZQ(dzs, q);
+                        const double rtl = mq[q] ? (wv - (lb[q] - cur[q]) - tl[q]) : 0.0;
+                        const double rtu = mq[q] ? ((ub[q] - cur[q]) - wv - tu[q]) : 0.0;
+                        const double itl = w.rcp(tl[q]), itu = w.rcp(tu[q]);
+                        // corrector targets from the affine step (recomputed, not kept in registers)
+                        const double atl = mq[q] ? (dwa + rtl) : 0.0, atu = mq[q] ? (-dwa + rtu) : 0.0;
+                        const double all_ = -ll[q] - ll[q] * itl * atl, alu = -lu[q] - lu[q] * itu * atu;
+                        const double ctl = smu - csc * atl * all_, ctu = smu - csc * atu * alu;
+                        const double dw = dwa + NMPC_ZQ(dzl, q);
+                        dtl[q] = mq[q] ? (dw + rtl) : 0.0;
+                        dtu[q] = mq[q] ? (-dw + rtu) : 0.0;
+                        dll[q] = mq[q] ? (ctl * itl - ll[q] - ll[q] * itl * dtl[q]) : 0.0;
+                        dlu[q] = mq[q] ? (ctu * itu - lu[q] - lu[q] * itu * dtu[q]) : 0.0;
+                        r_loc = fmax(r_loc, fmax(-dtl[q] * itl, -dtu[q] * itu));
                         r_loc = fmax(r_loc, mq[q] ? fmax(-dll[q] * w.rcp(ll[q]), -dlu[q] * w.rcp(lu[q])) : 0.0);
                     }
                     const double a_max = w.rcp(w.max(r_loc));
                     const double tau = fmax(pb.tau, 1.0 - mu_aff);
                     const double alpha = fmin(1.0, tau * a_max);
 #pragma unroll
-                    for (int m = 0; m < 8; ++m) z[m] += alpha * dzs[m];
+                    for (int m = 0; m < 8; ++m) z[m] += alpha * (dzs[m] + dzl[m]);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         tl[q] += alpha * dtl[q]; tu[q] += alpha * dtu[q];
                         ll[q] += alpha * dll[q]; lu[q] += alpha * dlu[q];
                     }
 #pragma unroll
-                    for (int m = 0; m < 6; ++m) L.rb[m] *= (1.0 - alpha);
+                    for (int m = 0; m < 6; ++m) rb[m] *= (1.0 - alpha);
                     lin_scale *= (1.0 - alpha);
                 }
             }
@@ -599,7 +658,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
         for (int m = 0; m < 6; ++m) xb[m] += z[2 + m];
         if (lane == 0) {
 #pragma unroll
-            for (int m = 0; m < 6; ++m) xb[m] = x0[m];
+            for (int m = 0; m < 6; ++m) xb[m] = io.x0[m];
         }
         status = qp_status;
         if (qp_status != 0) { ++sqp_it; break; }
@@ -633,5 +692,8 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
         *io.cost = cost_out;
     }
 }
+
+#undef NMPC_ZQ
+#undef NMPC_VCOL
 
 }  // namespace nmpcw

@@ -36,6 +36,7 @@ struct EmuWave {
     int lane_;
     int lane() const { return lane_; }
     double *lds() { return g_s->lds; }
+    int opaque(int v) { return v; }
     void sync()
     {
         g_s->nsync[lane_]++;

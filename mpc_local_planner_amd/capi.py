@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnmpc_hip.so")
+# NMPC_HIP_LIB selects another build of the same library (profiling variants, A/B runs)
+LIB_PATH = os.environ.get("NMPC_HIP_LIB") or os.path.join(_HERE, "libnmpc_hip.so")
 
 MODE_RTI, MODE_SQP = 0, 1
 OK, EINVAL, EHIP, ENOMEM = 0, -1, -2, -3

@@ -24,10 +24,18 @@ struct GpuWave {
     // value the optimiser must treat as unknown: keeps per-sweep address set-up inside the
     // interior-point loop instead of hoisted into ~45 live registers
     __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
-    // exchange through LDS between lanes of the single wave of this workgroup
-    __device__ __forceinline__ void sync() { __syncthreads(); }
-    // ordering that lock-step execution of one wave already provides
-    __device__ __forceinline__ void sync_lockstep() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+    // Exchange through LDS between lanes of the ONE wave of this workgroup (the launch uses
+    // 64-thread blocks only): the LDS executes a wave's instructions in issue order, so a
+    // write followed by a read needs no s_waitcnt and no s_barrier, only a fence that keeps
+    // the compiler from moving LDS accesses across the exchange point.
+    __device__ __forceinline__ void sync()
+    {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void sync_lockstep() { sync(); }
+    // keep the loads issued above this point together (one wait instead of one per load)
+    __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
     __device__ __forceinline__ double readlane(double v, int src)
     {
         const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);

@@ -36,6 +36,14 @@
 
 #include <math.h>
 
+// Profiling aids (tools/prof_variants.py builds throw-away libraries with these; the shipped
+// library defines neither): NMPC_PROF_FIXED_ITERS = run exactly that many interior-point
+// iterations, NMPC_PROF_SKIP = bit mask of sweeps to leave out (1 factor, 2 backward, 4 forward)
+// -- results are then meaningless, only the time difference is of interest.
+#ifndef NMPC_PROF_SKIP
+#define NMPC_PROF_SKIP 0
+#endif
+
 namespace nmpcw {
 
 struct Problem {            // uniform over the launch
@@ -66,7 +74,7 @@ struct InstanceIO {
 constexpr int ST = 44;          // per stage
 constexpr int O_BA = 0;         // [c][3]: columns u0,u1,psi,v,delta,thr x rows X,Y,psi of [B A]
 constexpr int O_KP = 18;        // (K0[c],K1[c]) c = X..thr, then (kff0,kff1)
-constexpr int O_INV = 32;       // i00,i01,i11,0
+constexpr int O_INV = 32;       // -inv(Huu): -i00,-i01,-i11,(pad)
 constexpr int O_D = 36;         // slot k: rb_k[6] -> z_{k+1}[8] = du,dx (forward sweeps) -> dG_k[4]
 constexpr int O_TAB = 18;       // input view of the factor sweep: gam[4],Q00,Q01,Q02,(unused)
 constexpr int O_G = 26;         //   G[8]
@@ -78,7 +86,7 @@ constexpr int C_ZERO = 24;      // 0,0,0,0
 constexpr int X_P = 0;          // Pt rows [6][8]: P[m][0..5], p[m], pad
 constexpr int X_M = 48;         // Mt col-major [9][6]
 constexpr int X_HU = 104;       // (Ht[0][j], Ht[1][j]) j = 0..8
-constexpr int X_V = 124;        // recursion vector of the backward sweep, double-buffered [2][6]
+constexpr int X_V = 124;        // (spare)
 constexpr int X_DUM = 136;      // dummy target for lanes with nothing to store
 constexpr int X_SIZE = 140;
 constexpr int lds_doubles(int N) { return (N + 1) * ST + X_SIZE; }
@@ -318,7 +326,11 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
             const double mu = w.sum(mu_loc) / mcount;
             const double cmax = w.max(c_loc);
             if (!(mu == mu)) { qp_status = 1; break; }
+#ifdef NMPC_PROF_FIXED_ITERS
+            if (it >= NMPC_PROF_FIXED_ITERS) { qp_status = 0; break; }
+#else
             if (it > 0 && mu <= pb.tol_mu && lin_scale <= pb.tol_lin && cmax <= pb.tol_comp) { qp_status = 0; break; }
+#endif
             if (it >= pb.ipm_max_iter) { qp_status = (mu <= 1e-8 && lin_scale <= 1e-8) ? 0 : 4; break; }
             {
                 double G[8];
@@ -427,31 +439,35 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 const double *tj = pTopJ, *bj = pBotJ, *ti = pTopI, *tb = pTab;
                 double *kw = pKw, *iw = pIw;
 #pragma unroll 1
-                for (int k = N - 1; k >= 0; --k) {
+                for (int k = (NMPC_PROF_SKIP & 1) ? -1 : N - 1; k >= 0; --k) {
+                    // stage data of phases 1 and 2 (independent of the recursion) and the Pt row
+                    const double t0 = tj[0], t1 = tj[1], t2 = tj[2], b0 = bj[0], b1 = bj[1], b2 = bj[2];
+                    const double r0 = pProw[0], r1 = pProw[1], r2 = pProw[2], r3 = pProw[3], r4 = pProw[4],
+                                 r5 = pProw[5], r6 = pProw[6];
+                    const double u0 = ti[0], u1 = ti[1], u2 = ti[2], v0 = pBotI[0], v1 = pBotI[1], v2 = pBotI[2];
+                    const double hc = hconst + *tb;
+                    w.sched_fence();
                     // phase 1: Mt[m][j] = Pt[m][0..5] . BAt[0..5][j] + p[m] [j == 8]
-                    double acc = pProw[6] * e8;
-                    acc = fma(pProw[0], tj[0], acc);
-                    acc = fma(pProw[1], tj[1], acc);
-                    acc = fma(pProw[2], tj[2], acc);
-                    acc = fma(pProw[3], bj[0], acc);
-                    acc = fma(pProw[4], bj[1], acc);
-                    acc = fma(pProw[5], bj[2], acc);
-                    *pMw = acc;
+                    double accA = r6 * e8, accB = r1 * t1;
+                    accA = fma(r0, t0, accA); accB = fma(r3, b0, accB);
+                    accA = fma(r2, t2, accA); accB = fma(r5, b2, accB);
+                    accA = fma(r4, b1, accA);
+                    *pMw = accA + accB;
                     w.sync();
                     // phase 2: Ht[i][j] = cost[i][j] + BAt[0..5][i] . Mt[0..5][j]
-                    double Hv = hconst + *tb;
-                    Hv = fma(ti[0], pMr[0], Hv);
-                    Hv = fma(ti[1], pMr[1], Hv);
-                    Hv = fma(ti[2], pMr[2], Hv);
-                    Hv = fma(pBotI[0], pMr[3], Hv);
-                    Hv = fma(pBotI[1], pMr[4], Hv);
-                    Hv = fma(pBotI[2], pMr[5], Hv);
+                    const double m0 = pMr[0], m1 = pMr[1], m2 = pMr[2], m3 = pMr[3], m4 = pMr[4], m5 = pMr[5];
+                    w.sched_fence();
+                    double HvA = fma(u0, m0, hc), HvB = u1 * m1;
+                    HvA = fma(u2, m2, HvA); HvB = fma(v0, m3, HvB);
+                    HvA = fma(v1, m4, HvA); HvB = fma(v2, m5, HvB);
+                    const double Hv = HvA + HvB;
                     *pHw1 = Hv;
                     *pHw2 = Hv;
                     w.sync();
                     // phase 3: eliminate the inputs
                     const double H00 = xa[X_HU + 0], H01 = xa[X_HU + 1], H11 = xa[X_HU + 3];
                     const double H0j = pHj[0], H1j = pHj[1], H0i = pHi[0], H1i = pHi[1];
+                    w.sched_fence();
                     const double rdet = w.rcp(H00 * H11 - H01 * H01);
                     const double i00 = H11 * rdet, i01 = -H01 * rdet, i11 = H00 * rdet;
                     const double K0 = -(i00 * H0j + i01 * H1j), K1 = -(i01 * H0j + i11 * H1j);
@@ -459,7 +475,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     *pPw1 = Pn;
                     *pPw2 = Pn;
                     kw[0] = K0; kw[1] = K1;
-                    iw[0] = i00; iw[1] = i01; iw[2] = i11;
+                    iw[0] = -i00; iw[1] = -i01; iw[2] = -i11;   // the backward sweep wants -inv
                     w.sync();
                     tj -= sTopJ; bj -= sBotJ; ti -= sTopI; tb -= sTab; kw -= sKw; iw -= sIw;
                 }
@@ -472,10 +488,11 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
 #pragma unroll 1
             for (int pass = 0; pass < 2; ++pass) {
                 if (pass == 1) {
-                    // backward vector sweep: lane component vc, p replicated
-                    double p6[6] = {0, 0, 0, 0, 0, 0};
+                    // backward vector sweep (corrector right-hand side, homogeneous dynamics): lane vl
+                    // owns z component vl, the recursion vector p is wave-uniform (re-gathered with
+                    // readlane: no LDS round trip on the serial path)
                     const int vl = w.opaque(lane) & 7;
-                    const double *tv;                // column vl, rows X,Y,psi
+                    const double *tv;                 // column vl of [B A], rows X,Y,psi
                     int sTopV;
                     if (vl == 2 || vl == 3) { tv = ct + C_UNIT + 3 * (vl - 2); sTopV = 0; }
                     else { tv = last + O_BA + 3 * NMPC_VCOL(vl); sTopV = ST; }
@@ -483,70 +500,70 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     int sDgV = 0;
                     if (vl < 2) { dg = last + O_D + vl; sDgV = ST; }
                     if (vl >= 6) { dg = last + O_D + vl - 4; sDgV = ST; }
-                    const double *kp = last + O_KP + 2 * (vl >= 2 ? vl - 2 : 0);
+                    // res = keep * hc + ab[0] * hu0 + ab[1] * hu1: lanes >= 2 form p_new with their gain
+                    // pair (K0,K1); lanes 0,1 form kff = -(inv hu) with row vl of -inv
+                    const double *ab = vl >= 2 ? last + O_KP + 2 * (vl - 2) : last + O_INV + vl;
+                    const double keep = vl >= 2 ? 1.0 : 0.0;
+                    double *kfw = w.opaque(lane) < 2 ? last + O_KP + 12 + vl : xa + X_DUM;
+                    const int sKfw = w.opaque(lane) < 2 ? ST : 0;
                     // rows v,delta,thr of column vl
                     const double cb0 = vl == 1 ? b31 : vl == 5 ? a33 : vl == 7 ? a35 : 0.0;
                     const double cb1 = vl == 0 ? h : vl == 6 ? 1.0 : 0.0;
                     const double cb2 = vl == 1 ? h : vl == 7 ? 1.0 : 0.0;
-                    double *sl = last;
+                    double p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0;
 #pragma unroll 1
-                    for (int k = N - 1; k >= 0; --k) {
-                        double hc = *dg;
-                        hc = fma(tv[0], p6[0], hc);
-                        hc = fma(tv[1], p6[1], hc);
-                        hc = fma(tv[2], p6[2], hc);
-                        hc = fma(cb0, p6[3], hc);
-                        hc = fma(cb1, p6[4], hc);
-                        hc = fma(cb2, p6[5], hc);
+                    for (int k = (NMPC_PROF_SKIP & 2) ? -1 : N - 1; k >= 0; --k) {
+                        const double dgv = *dg, t0 = tv[0], t1 = tv[1], t2 = tv[2], ka = ab[0], kb = ab[1];
+                        w.sched_fence();
+                        double hA = fma(t0, p0, dgv), hB = t1 * p1;
+                        hA = fma(t2, p2, hA); hB = fma(cb0, p3, hB);
+                        hA = fma(cb1, p4, hA); hB = fma(cb2, p5, hB);
+                        const double hc = hA + hB;
                         const double hu0 = w.readlane(hc, 0), hu1 = w.readlane(hc, 1);
-                        const double pn = hc + kp[0] * hu0 + kp[1] * hu1;
-                        double *xv = xa + X_V + (k & 1) * 6;
-                        if (vl >= 2) xv[vl - 2] = pn;
-                        const double i00 = sl[O_INV + 0], i01 = sl[O_INV + 1], i11 = sl[O_INV + 2];
-                        if (lane == 0) {
-                            sl[O_KP + 12] = -(i00 * hu0 + i01 * hu1);
-                            sl[O_KP + 13] = -(i01 * hu0 + i11 * hu1);
-                        }
-                        w.sync();
-#pragma unroll
-                        for (int m = 0; m < 6; ++m) p6[m] = xv[m];
-                        tv -= sTopV; dg -= sDgV; kp -= ST; sl -= ST;
+                        const double res = fma(kb, hu1, fma(ka, hu0, keep * hc));
+                        *kfw = res;
+                        p0 = w.readlane(res, 2); p1 = w.readlane(res, 3); p2 = w.readlane(res, 4);
+                        p3 = w.readlane(res, 5); p4 = w.readlane(res, 6); p5 = w.readlane(res, 7);
+                        tv -= sTopV; dg -= sDgV; ab -= ST; kfw -= sKfw;
                     }
+                    w.sync();
                 }
-                // forward sweep: du uniform, lane row vr of dx+, z_k stored in slot k-1
+                // forward sweep: lane vl computes row vr of dx+ and input (vl & 1); z_k is stored in
+                // slot k-1 (its r_b has been consumed), dx is wave-uniform
                 {
                     const double rbs = pass == 0 ? 1.0 : 0.0;
-                    double dx[6] = {0, 0, 0, 0, 0, 0};
-                    const int vl = w.opaque(lane) & 7;
-                    const int vr = vl < 6 ? vl : 5;     // row vr of [B A] (lanes 6,7 duplicate row 5)
+                    const int fl = w.opaque(lane);
+                    const int vl = fl & 7;
+                    const int vr = vl < 6 ? vl : 5;     // lanes 6,7 duplicate row 5
                     const double *rw = vr < 3 ? stg + O_BA + vr : ct + C_BOT + (vr - 3);
                     const int sRowV = vr < 3 ? ST : 0;
                     const double eX = vr == 0 ? 1.0 : 0.0, eY = vr == 1 ? 1.0 : 0.0;
-                    double *sl = stg;
+                    const double *kr = stg + O_KP + (vl & 1);     // K_a[c] at kr[2c], kff_a at kr[12]
+                    const double *rbp = stg + O_D + vr;
+                    double *dnw = stg + O_D + 2 + vr;             // dx_{k+1}[vr] -> slot k
+                    double *duw = fl < 2 ? ct + O_D + fl : xa + X_DUM;   // du_k[a] -> slot k-1
+                    const int sDuw = fl < 2 ? ST : 0;
+                    double x0 = 0, x1 = 0, x2 = 0, x3 = 0, x4 = 0, x5 = 0;
 #pragma unroll 1
-                    for (int k = 0; k < N; ++k) {
-                        double du0 = sl[O_KP + 12], du1 = sl[O_KP + 13];
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) {
-                            du0 = fma(sl[O_KP + 2 * c], dx[c], du0);
-                            du1 = fma(sl[O_KP + 2 * c + 1], dx[c], du1);
-                        }
-                        double dn = rbs * sl[O_D + vr];
-                        dn = fma(eX, dx[0], dn);
-                        dn = fma(eY, dx[1], dn);
-                        dn = fma(rw[0], du0, dn);
-                        dn = fma(rw[3], du1, dn);
-                        dn = fma(rw[6], dx[2], dn);
-                        dn = fma(rw[9], dx[3], dn);
-                        dn = fma(rw[12], dx[4], dn);
-                        dn = fma(rw[15], dx[5], dn);
-                        w.sync_lockstep();          // every lane has read r_b of this slot
-                        sl[O_D + 2 + vr] = dn;      // dx_{k+1}
-                        if (lane == 0) { sl[O_D - ST] = du0; sl[O_D - ST + 1] = du1; }   // du_k, beside dx_k
-                        w.sync();
-#pragma unroll
-                        for (int m = 0; m < 6; ++m) dx[m] = sl[O_D + 2 + m];
-                        rw += sRowV; sl += ST;
+                    for (int k = (NMPC_PROF_SKIP & 4) ? N : 0; k < N; ++k) {
+                        const double k0 = kr[0], k1 = kr[2], k2 = kr[4], k3 = kr[6], k4 = kr[8], k5 = kr[10], kf = kr[12];
+                        const double b0 = rw[0], b1 = rw[3], a2 = rw[6], a3 = rw[9], a4 = rw[12], a5 = rw[15];
+                        const double rbv = *rbp;
+                        w.sched_fence();
+                        double uA = fma(k0, x0, kf), uB = k1 * x1;
+                        uA = fma(k2, x2, uA); uB = fma(k3, x3, uB);
+                        uA = fma(k4, x4, uA); uB = fma(k5, x5, uB);
+                        const double dua = uA + uB;
+                        double rA = fma(eX, x0, rbs * rbv), rB = eY * x1;
+                        rA = fma(a2, x2, rA); rB = fma(a3, x3, rB);
+                        rA = fma(a4, x4, rA); rB = fma(a5, x5, rB);
+                        const double du0 = w.readlane(dua, 0), du1 = w.readlane(dua, 1);
+                        const double dn = fma(b1, du1, fma(b0, du0, rA + rB));
+                        *dnw = dn;
+                        *duw = dua;
+                        x0 = w.readlane(dn, 0); x1 = w.readlane(dn, 1); x2 = w.readlane(dn, 2);
+                        x3 = w.readlane(dn, 3); x4 = w.readlane(dn, 4); x5 = w.readlane(dn, 5);
+                        rw += sRowV; kr += ST; rbp += ST; dnw += ST; duw += sDuw;
                     }
                     if (lane == 0) {                // z_0 = (du_0, 0): dx_0 is folded into r_b
 #pragma unroll

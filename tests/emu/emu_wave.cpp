@@ -37,6 +37,7 @@ struct EmuWave {
     int lane() const { return lane_; }
     double *lds() { return g_s->lds; }
     int opaque(int v) { return v; }
+    void sched_fence() {}
     void sync()
     {
         g_s->nsync[lane_]++;

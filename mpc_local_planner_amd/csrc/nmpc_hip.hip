@@ -34,6 +34,39 @@ struct GpuWave {
         __builtin_amdgcn_wave_barrier();
     }
     __device__ __forceinline__ void sync_lockstep() { sync(); }
+    // forward-sweep stage data: kr[0,2,..,12], rw[0,4,..,20], rbp[0] as 14 x ds_read_b64 and one wait.
+    // Written in asm because the compiler merges such loads into ds_read2_b64 (8 LDS cycles per
+    // pair instead of 2+2) and offers no switch against it.
+    __device__ __forceinline__ void lds_gather_fwd(const double *kr, const double *rw, const double *rbp,
+                                                   double (&kk)[7], double (&rr)[6], double *rbv)
+    {
+        typedef __attribute__((address_space(3))) const double lds_cd;
+        const unsigned ak = (unsigned)(unsigned long long)(lds_cd *)kr;
+        const unsigned ar = (unsigned)(unsigned long long)(lds_cd *)rw;
+        const unsigned ab = (unsigned)(unsigned long long)(lds_cd *)rbp;
+        double v;
+        asm volatile(
+            "ds_read_b64 %0, %14\n\t"
+            "ds_read_b64 %1, %14 offset:16\n\t"
+            "ds_read_b64 %2, %14 offset:32\n\t"
+            "ds_read_b64 %3, %14 offset:48\n\t"
+            "ds_read_b64 %4, %14 offset:64\n\t"
+            "ds_read_b64 %5, %14 offset:80\n\t"
+            "ds_read_b64 %6, %14 offset:96\n\t"
+            "ds_read_b64 %7, %15\n\t"
+            "ds_read_b64 %8, %15 offset:32\n\t"
+            "ds_read_b64 %9, %15 offset:64\n\t"
+            "ds_read_b64 %10, %15 offset:96\n\t"
+            "ds_read_b64 %11, %15 offset:128\n\t"
+            "ds_read_b64 %12, %15 offset:160\n\t"
+            "ds_read_b64 %13, %16\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(kk[0]), "=&v"(kk[1]), "=&v"(kk[2]), "=&v"(kk[3]), "=&v"(kk[4]), "=&v"(kk[5]), "=&v"(kk[6]),
+              "=&v"(rr[0]), "=&v"(rr[1]), "=&v"(rr[2]), "=&v"(rr[3]), "=&v"(rr[4]), "=&v"(rr[5]), "=&v"(v)
+            : "v"(ak), "v"(ar), "v"(ab)
+            : "memory");
+        *rbv = v;
+    }
     // keep the loads issued above this point together (one wait instead of one per load)
     __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
     __device__ __forceinline__ double readlane(double v, int src)

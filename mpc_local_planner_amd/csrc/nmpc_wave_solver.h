@@ -555,12 +555,12 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     double x0 = 0, x1 = 0, x2 = 0, x3 = 0, x4 = 0, x5 = 0;
 #pragma unroll 1
                     for (int k = (NMPC_PROF_SKIP & 4) ? N : 0; k < N; ++k) {
-                        // single 8-byte loads on purpose (ld1): strided, and merged pairs are 4x slower
-                        const double k0 = ld1(kr), k1 = ld1(kr + 2), k2 = ld1(kr + 4), k3 = ld1(kr + 6),
-                                     k4 = ld1(kr + 8), k5 = ld1(kr + 10), kf = ld1(kr + 12);
-                        const double b0 = ld1(rw), b1 = ld1(rw + 4), a2 = ld1(rw + 8), a3 = ld1(rw + 12),
-                                     a4 = ld1(rw + 16), a5 = ld1(rw + 20);
-                        const double rbv = ld1(rbp);
+                        // 14 single 8-byte loads, strided: kept as ds_read_b64 (the pairs the compiler would
+                        // merge them into cost 4x the LDS cycles)
+                        double kk[7], rr[6], rbv;
+                        w.lds_gather_fwd(kr, rw, rbp, kk, rr, &rbv);
+                        const double k0 = kk[0], k1 = kk[1], k2 = kk[2], k3 = kk[3], k4 = kk[4], k5 = kk[5], kf = kk[6];
+                        const double b0 = rr[0], b1 = rr[1], a2 = rr[2], a3 = rr[3], a4 = rr[4], a5 = rr[5];
                         w.sched_fence();
                         double uA = fma(k0, x0, kf), uB = k1 * x1;
                         uA = fma(k2, x2, uA); uB = fma(k3, x3, uB);

@@ -38,6 +38,13 @@ struct EmuWave {
     double *lds() { return g_s->lds; }
     int opaque(int v) { return v; }
     void sched_fence() {}
+    void lds_gather_fwd(const double *kr, const double *rw, const double *rbp, double (&kk)[7],
+                        double (&rr)[6], double *rbv)
+    {
+        for (int c = 0; c < 7; ++c) kk[c] = kr[2 * c];
+        for (int c = 0; c < 6; ++c) rr[c] = rw[4 * c];
+        *rbv = *rbp;
+    }
     void sync()
     {
         g_s->nsync[lane_]++;

@@ -76,17 +76,31 @@ struct GpuWave {
         return __hiloint2double(hi, lo);
     }
     __device__ __forceinline__ double shfl_down1(double v) { return __shfl_down(v, 1, 64); }
+    // Wave-wide reductions without LDS traffic: four DPP butterfly steps (xor 1, xor 2, mirror
+    // within 8, mirror within 16) leave each 16-lane row's result in all its lanes; the four row
+    // results are then read with v_readlane and combined (uniform result).
+    template <int CTRL>
+    __device__ __forceinline__ static double dpp(double v)
+    {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    }
     __device__ __forceinline__ double sum(double v)
     {
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-        return v;
+        v += dpp<0xB1>(v);     // quad_perm [1,0,3,2]
+        v += dpp<0x4E>(v);     // quad_perm [2,3,0,1]
+        v += dpp<0x141>(v);    // row_half_mirror
+        v += dpp<0x140>(v);    // row_mirror
+        return (readlane(v, 0) + readlane(v, 16)) + (readlane(v, 32) + readlane(v, 48));
     }
     __device__ __forceinline__ double max(double v)
     {
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-        return v;
+        v = fmax(v, dpp<0xB1>(v));
+        v = fmax(v, dpp<0x4E>(v));
+        v = fmax(v, dpp<0x141>(v));
+        v = fmax(v, dpp<0x140>(v));
+        return fmax(fmax(readlane(v, 0), readlane(v, 16)), fmax(readlane(v, 32), readlane(v, 48)));
     }
     // reciprocal to ~1 ulp: hardware seed + two Newton steps (no div_scale/div_fixup sequence;
     // operands here are never subnormal or huge)

@@ -74,7 +74,7 @@ struct EmuWave {
         sync();
         double t[WAVE];
         memcpy(t, g_s->tmp, sizeof(t));
-        for (int o = 32; o >= 1; o >>= 1)   // same butterfly order as the GPU policy
+        for (int o = 32; o >= 1; o >>= 1)   // a butterfly like the GPU policy (association differs: round-off only)
             for (int l = 0; l < WAVE; ++l)
                 if ((l & o) == 0) { const double a = t[l] + t[l | o]; t[l] = a; t[l | o] = a; }
         sync();

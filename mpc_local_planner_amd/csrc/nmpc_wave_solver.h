@@ -368,12 +368,14 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 }
                 if (act) {
                     double *sl = stg + lane * ST;
-                    sl[O_TAB + 0] = gam[0]; sl[O_TAB + 1] = gam[1]; sl[O_TAB + 2] = gam[2]; sl[O_TAB + 3] = gam[3];
-                    sl[O_TAB + 4] = Q00;    sl[O_TAB + 5] = Q01;    sl[O_TAB + 6] = Q02;
+                    // 16-byte stores: with the stage stride of 100 dwords they are bank-conflict free
+                    // across lanes (8-byte accesses are 2-way)
+                    st2(sl + O_TAB + 0, gam[0], gam[1]); st2(sl + O_TAB + 2, gam[2], gam[3]);
+                    st2(sl + O_TAB + 4, Q00, Q01);       st2(sl + O_TAB + 6, Q02, 0.0);
 #pragma unroll
-                    for (int m = 0; m < 8; ++m) sl[O_G + m] = G[m];
-#pragma unroll
-                    for (int m = 0; m < 6; ++m) sl[O_D + (m < 3 ? m : m + 1)] = rb[m];
+                    for (int m = 0; m < 8; m += 2) st2(sl + O_G + m, G[m], G[m + 1]);
+                    st2(sl + O_D + 0, rb[0], rb[1]); st2(sl + O_D + 2, rb[2], 0.0);
+                    st2(sl + O_D + 4, rb[3], rb[4]); st2(sl + O_D + 6, rb[5], 0.0);
                 }
             }
             // terminal cost-to-go: none (no *_e cost or bound in mpcPathTracking.py)
@@ -588,7 +590,11 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 {
                     const double *src = ct + node * ST + O_D;
 #pragma unroll
-                    for (int m = 0; m < 8; ++m) dzl[m] = has_node ? src[m] : 0.0;
+                    for (int m = 0; m < 8; m += 2) {
+                        const D2 v = ld2(src + m);
+                        dzl[m] = has_node ? v.x : 0.0;
+                        dzl[m + 1] = has_node ? v.y : 0.0;
+                    }
                     if (!act) { dzl[0] = 0.0; dzl[1] = 0.0; }
                 }
                 if (pass == 0) {
@@ -627,11 +633,13 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     // (the pick-up reads above are ordered before these stores by the reductions)
                     if (act) {
                         double *sl = stg + lane * ST + O_D;
+                        double dG[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const double ctl = smu - csc * dtl[q] * dll[q], ctu = smu - csc * dtu[q] * dlu[q];
-                            sl[q] = mq[q] ? (-ctl * itl[q] + ctu * itu[q]) : 0.0;
+                            dG[q] = mq[q] ? (-ctl * itl[q] + ctu * itu[q]) : 0.0;
                         }
+                        st2(sl, dG[0], dG[1]); st2(sl + 2, dG[2], dG[3]);
                     }
                     w.sync();
                 } else {

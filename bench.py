@@ -112,7 +112,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from mpc_local_planner_amd import capi, scenarios as sc
+    from mpc_local_planner_amd import capi, scenarios as sc, sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -125,7 +125,8 @@ def main():
 
     N, B = args.horizon, args.batch
     solver = capi.BatchSolver(N=N, dt=0.35, capacity=B, device=local_rank)
-    x0, p = sc.config2(B, start=rank * B)        # this rank's shard of the global batch
+    start, stop = sharding.shard_range(rank, world, world * B)   # this rank's block of the global batch
+    x0, p = sc.config2(stop - start, start=start)
     solver.set_x0(x0)
     solver.set_params(p)                         # inputs now resident in HBM
     hip = Hip()
@@ -136,8 +137,7 @@ def main():
         def __init__(self, ptr, n):
             self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False),
                                              "version": 2}
-    ctrl_local = torch.as_tensor(_Arr(solver.device_ptr(0), B * 6), device=f"cuda:{local_rank}")
-    ctrl_all = torch.empty(world * B * 6, dtype=torch.float64, device=f"cuda:{local_rank}") if world > 1 else None
+    ctrl_local = torch.as_tensor(_Arr(solver.device_ptr(0), B * 6), device=f"cuda:{local_rank}").reshape(B, 6)
 
     def barrier():
         solver.sync()
@@ -156,7 +156,7 @@ def main():
                 hip.record(events[2 * s + 1], stream)
             if gather and world > 1:
                 solver.sync()
-                dist.all_gather_into_tensor(ctrl_all, ctrl_local)
+                sharding.gather_controls(ctrl_local, total=world * B)
 
     def timed(steps, cold, gather, with_events=False):
         events = [hip.event() for _ in range(2 * steps)] if with_events else None

@@ -36,7 +36,7 @@ extern "C" {
 #define NMPC_MODE_SQP 1    /* nlp_solver_type SQP */
 
 typedef struct nmpc_config {
-    int N;              /* mpc_N   (config/mpc_params.yaml:35); 1 <= N <= 63 */
+    int N;              /* mpc_N   (config/mpc_params.yaml:35); 1 <= N <= 127 */
     double dt;          /* mpc_dt  (:41) */
     double wheelbase;   /* (:59) */
     double W[7];        /* diag of ocp.cost.W (acados/mpcPathTracking.py:103) */

@@ -17,23 +17,34 @@ namespace {
 
 // ------------------------------------------------------------------ device side
 
+// NW = waves per OCP instance (= per workgroup): 1 for N <= 63, 2 for N <= 127.  The sweeps always
+// run on the first wave; the other wave only takes part in the stage-layout work.
+template <int NW>
 struct GpuWave {
     double *lds_;
-    __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }
+    double *pol_;      // NW > 1: [2][4] reduction slots, then [128] exchange slots
+    int flip_ = 0;
+    __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
+    __device__ __forceinline__ int lane() const { return (int)threadIdx.x & 63; }
+    __device__ __forceinline__ bool sweep_wave() const { return NW == 1 || threadIdx.x < 64; }
     __device__ __forceinline__ double *lds() { return lds_; }
     // value the optimiser must treat as unknown: keeps per-sweep address set-up inside the
     // interior-point loop instead of hoisted into ~45 live registers
     __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
-    // Exchange through LDS between lanes of the ONE wave of this workgroup (the launch uses
-    // 64-thread blocks only): the LDS executes a wave's instructions in issue order, so a
-    // write followed by a read needs no s_waitcnt and no s_barrier, only a fence that keeps
-    // the compiler from moving LDS accesses across the exchange point.
-    __device__ __forceinline__ void sync()
+    // Exchange through LDS between lanes of ONE wave: the LDS executes a wave's instructions in
+    // issue order, so a write followed by a read needs no s_waitcnt and no s_barrier, only a
+    // fence that keeps the compiler from moving LDS accesses across the exchange point.
+    __device__ __forceinline__ void wsync()
     {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    __device__ __forceinline__ void sync_lockstep() { sync(); }
+    // exchange between all threads of the instance
+    __device__ __forceinline__ void sync()
+    {
+        if (NW == 1) wsync(); else __syncthreads();
+    }
+    __device__ __forceinline__ void sync_lockstep() { wsync(); }
     // forward-sweep stage data: kr[0,2,..,12], rw[0,4,..,20], rbp[0] as 14 x ds_read_b64 and one wait.
     // Written in asm because the compiler merges such loads into ds_read2_b64 (8 LDS cycles per
     // pair instead of 2+2) and offers no switch against it.
@@ -69,16 +80,27 @@ struct GpuWave {
     }
     // keep the loads issued above this point together (one wait instead of one per load)
     __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+    // value of lane `src` of the calling wave (uniform)
     __device__ __forceinline__ double readlane(double v, int src)
     {
         const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
         const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
         return __hiloint2double(hi, lo);
     }
-    __device__ __forceinline__ double shfl_down1(double v) { return __shfl_down(v, 1, 64); }
-    // Wave-wide reductions without LDS traffic: four DPP butterfly steps (xor 1, xor 2, mirror
-    // within 8, mirror within 16) leave each 16-lane row's result in all its lanes; the four row
-    // results are then read with v_readlane and combined (uniform result).
+    // value of thread tid+1 (the last thread gets its own)
+    __device__ __forceinline__ double shfl_down1(double v)
+    {
+        if (NW == 1) return __shfl_down(v, 1, 64);
+        double *ex = pol_ + 8;
+        ex[threadIdx.x] = v;
+        __syncthreads();
+        const double r = ex[threadIdx.x + 1 < 64 * NW ? threadIdx.x + 1 : threadIdx.x];
+        __syncthreads();
+        return r;
+    }
+    // Reductions over all threads of the instance without LDS traffic inside a wave: four DPP
+    // butterfly steps (xor 1, xor 2, mirror within 8, mirror within 16) leave each 16-lane row's
+    // result in all its lanes; the four row results are read with v_readlane and combined.
     template <int CTRL>
     __device__ __forceinline__ static double dpp(double v)
     {
@@ -86,13 +108,28 @@ struct GpuWave {
         const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
         return __hiloint2double(hi, lo);
     }
+    // partial results of the waves meet in LDS; slots alternate so one barrier per call is enough
+    template <class OP>
+    __device__ __forceinline__ double across_waves(double s, OP op)
+    {
+        if (NW == 1) return s;
+        double *slot = pol_ + (flip_ & 1) * 4;
+        flip_ ^= 1;
+        if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = s;
+        __syncthreads();
+        double r = slot[0];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) r = op(r, slot[i]);
+        return r;
+    }
     __device__ __forceinline__ double sum(double v)
     {
         v += dpp<0xB1>(v);     // quad_perm [1,0,3,2]
         v += dpp<0x4E>(v);     // quad_perm [2,3,0,1]
         v += dpp<0x141>(v);    // row_half_mirror
         v += dpp<0x140>(v);    // row_mirror
-        return (readlane(v, 0) + readlane(v, 16)) + (readlane(v, 32) + readlane(v, 48));
+        const double s = (readlane(v, 0) + readlane(v, 16)) + (readlane(v, 32) + readlane(v, 48));
+        return across_waves(s, [](double a, double b) { return a + b; });
     }
     __device__ __forceinline__ double max(double v)
     {
@@ -100,7 +137,8 @@ struct GpuWave {
         v = fmax(v, dpp<0x4E>(v));
         v = fmax(v, dpp<0x141>(v));
         v = fmax(v, dpp<0x140>(v));
-        return fmax(fmax(readlane(v, 0), readlane(v, 16)), fmax(readlane(v, 32), readlane(v, 48)));
+        const double s = fmax(fmax(readlane(v, 0), readlane(v, 16)), fmax(readlane(v, 32), readlane(v, 48)));
+        return across_waves(s, [](double a, double b) { return fmax(a, b); });
     }
     // reciprocal to ~1 ulp: hardware seed + two Newton steps (no div_scale/div_fixup sequence;
     // operands here are never subnormal or huge)
@@ -122,7 +160,8 @@ struct KernelArgs {
     unsigned char *reset;
 };
 
-__global__ void __launch_bounds__(64, 2) nmpc_solve_kernel(KernelArgs a)
+template <int NW>
+__global__ void __launch_bounds__(64 * NW, 2) nmpc_solve_kernel(KernelArgs a)
 {
     extern __shared__ double lds[];
     const int inst = (int)blockIdx.x;
@@ -139,7 +178,7 @@ __global__ void __launch_bounds__(64, 2) nmpc_solve_kernel(KernelArgs a)
     io.sqp_iters = a.sqp_iters + inst;
     io.cost = a.cost + inst;
     io.cold = a.reset[inst];
-    GpuWave w{lds};
+    GpuWave<NW> w{lds, lds + (a.pb.N + 1) * nmpcw::ST + nmpcw::X_SIZE};
     nmpcw::solve_instance(w, a.pb, io);
     // failed instances restart cold next time (reference: reInit on status != 0,
     // src/AcadosSolver.cpp:56-59); successful ones keep their iterate (warm start)
@@ -241,7 +280,7 @@ static int fill_defaults(nmpc_handle *h, bool weights, bool bounds)
 int nmpc_create(const nmpc_config *cfg, int capacity, int device, nmpc_handle **out)
 {
     if (!cfg || !out || capacity <= 0) return NMPC_EINVAL;
-    if (cfg->N < 1 || cfg->N > 63 || !(cfg->dt > 0.0) || !(cfg->wheelbase > 0.0)) return NMPC_EINVAL;
+    if (cfg->N < 1 || cfg->N > 127 || !(cfg->dt > 0.0) || !(cfg->wheelbase > 0.0)) return NMPC_EINVAL;
     *out = nullptr;
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -273,10 +312,12 @@ int nmpc_create(const nmpc_config *cfg, int capacity, int device, nmpc_handle **
     if (ok) ok = fill_defaults(h, true, true) == NMPC_OK;
     if (ok) {
         const int lds_bytes = nmpcw::lds_doubles(cfg->N) * (int)sizeof(double);
-        if (lds_bytes > 64 * 1024)
-            ok = hip_ok(hipFuncSetAttribute((const void *)nmpc_solve_kernel,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes),
+        if (lds_bytes > 48 * 1024) {
+            const void *fn = nmpcw::waves_per_instance(cfg->N) == 1 ? (const void *)nmpc_solve_kernel<1>
+                                                                    : (const void *)nmpc_solve_kernel<2>;
+            ok = hip_ok(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes),
                         "hipFuncSetAttribute");
+        }
     }
     if (!ok) {
         for (auto &a : allocs) if (*a.p) (void)hipFree(*a.p);
@@ -408,7 +449,11 @@ int nmpc_solve(nmpc_handle *h, int B, int mode, int max_iter, double tol)
     a.status = h->d_status; a.iters = h->d_iters; a.sqp_iters = h->d_sqp;
     a.reset = h->d_reset;
     const size_t lds_bytes = (size_t)nmpcw::lds_doubles(h->cfg.N) * sizeof(double);
-    hipLaunchKernelGGL(nmpc_solve_kernel, dim3(B), dim3(64), lds_bytes, h->stream, a);
+    // one workgroup per instance: one wave (lane = shooting node) up to N = 63, two waves beyond
+    if (nmpcw::waves_per_instance(h->cfg.N) == 1)
+        hipLaunchKernelGGL(nmpc_solve_kernel<1>, dim3(B), dim3(64), lds_bytes, h->stream, a);
+    else
+        hipLaunchKernelGGL(nmpc_solve_kernel<2>, dim3(B), dim3(128), lds_bytes, h->stream, a);
     HIP_TRY(hipGetLastError());
     return NMPC_OK;
 }

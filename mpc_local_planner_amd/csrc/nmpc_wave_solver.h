@@ -47,7 +47,7 @@
 namespace nmpcw {
 
 struct Problem {            // uniform over the launch
-    int N;                  // horizon, N+1 <= 64
+    int N;                  // horizon, N+1 <= 64 * waves per instance (<= 128)
     double dt;              // shooting interval
     double inv_wheelbase;   // 1/L
     int ipm_max_iter;
@@ -91,7 +91,11 @@ constexpr int X_M = 48;         // Mt col-major [9][6] (+ slack read by the idle
 constexpr int X_HU = 116;       // (Ht[0][j], Ht[1][j]) j = 0..8, then the unit columns (1,0),(0,1)
 constexpr int X_DUM = 138;      // dummy target for lanes with nothing to store
 constexpr int X_SIZE = 142;
-constexpr int lds_doubles(int N) { return (N + 1) * ST + X_SIZE; }
+// horizons beyond 63 use two waves per instance (lane = node needs 128 threads); their cross-wave
+// reductions and the x_{k+1} hand-over go through a small extra area owned by the wave policy
+constexpr int X_POLICY = 8 + 128;
+constexpr int waves_per_instance(int N) { return N + 1 <= 64 ? 1 : 2; }
+constexpr int lds_doubles(int N) { return (N + 1) * ST + X_SIZE + (waves_per_instance(N) > 1 ? X_POLICY : 0); }
 
 // 16-byte pair access (ds_read_b128 / ds_write_b128) and a single load that is never merged
 struct alignas(16) D2 { double x, y; };
@@ -193,7 +197,8 @@ NMPC_DEV void rk4_sens(const Problem &pb, const double *x, const double *u, doub
 template <class W>
 NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
 {
-    const int lane = w.lane();
+    const int tid = w.tid();     // thread in the workgroup = shooting node in stage layout
+    const int lane = w.lane();   // lane in the wave (the sweeps run on the first wave only)
     const int N = pb.N;
     const double h = pb.dt;
     double *const ct = w.lds();                 // pseudo-stage -1 (constant tables, z_0)
@@ -201,10 +206,10 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
     double *const xa = ct + (N + 1) * ST;       // exchange area
 
     // ---------------------------------------------------------------- iterate (stage layout)
-    const bool has_node = lane <= N;       // lanes 0..N hold x_k
-    const bool act = lane < N;             // lanes 0..N-1 hold u_k and a shooting interval
-    const bool actx = act && lane >= 1;    // state bounds exist on nodes 1..N-1 only
-    const int node = has_node ? lane : N;
+    const bool has_node = tid <= N;        // threads 0..N hold x_k
+    const bool act = tid < N;              // threads 0..N-1 hold u_k and a shooting interval
+    const bool actx = act && tid >= 1;     // state bounds exist on nodes 1..N-1 only
+    const int node = has_node ? tid : N;
     double xb[6], ub_[2];                   // NLP iterate of this node
     {
         const double *t = io.traj + node * 8;
@@ -241,7 +246,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 const double xn = w.shfl_down1(xb[m]);       // x_{k+1} from the next lane
                 rb[m] = act ? (phi[m] - xn) : 0.0;
             }
-            if (lane == 0) {   // fold the known dx_0 = x0 - x_0 into the first gap: b_0 += A_0 dx0
+            if (tid == 0) {   // fold the known dx_0 = x0 - x_0 into the first gap: b_0 += A_0 dx0
                 double d[6];
 #pragma unroll
                 for (int m = 0; m < 6; ++m) d[m] = io.x0[m] - xb[m];
@@ -253,7 +258,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 rb[5] += d[5];
             }
             if (act) {   // variable rows X,Y,psi of [B A], column-major, columns u0,u1,psi,v,delta,thr
-                double *c = stg + lane * ST + O_BA;
+                double *c = stg + tid * ST + O_BA;
                 st2(c + 0, aX[4], aY[4]);  st2(c + 2, aP[4], 0.0);
                 st2(c + 4, aX[5], aY[5]);  st2(c + 6, aP[5], 0.0);
                 st2(c + 8, aX[0], aY[0]);  st2(c + 10, aP[0], 0.0);
@@ -262,8 +267,8 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 st2(c + 20, aX[3], aY[3]); st2(c + 22, aP[3], 0.0);
             }
             if (!tables_ready) {   // constant rows (v,delta,thr) of [B A]: identical on every lane
-                a33 = w.readlane(aV[1], 0); a35 = w.readlane(aV[3], 0); b31 = w.readlane(aV[5], 0);
-                if (lane == 0) {
+                a33 = aV[1]; a35 = aV[3]; b31 = aV[5];   // functions of dt only
+                if (tid == 0) {
                     double *c = ct + C_BOT;
                     c[0] = 0.0;  c[1] = h;    c[2] = 0.0;  c[3] = 0.0;     // u0
                     c[4] = b31;  c[5] = 0.0;  c[6] = h;    c[7] = 0.0;     // u1
@@ -367,7 +372,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     if (q == 3) G[7] += gq;
                 }
                 if (act) {
-                    double *sl = stg + lane * ST;
+                    double *sl = stg + tid * ST;
                     // 16-byte stores: with the stage stride of 100 dwords they are bank-conflict free
                     // across lanes (8-byte accesses are 2-way)
                     st2(sl + O_TAB + 0, gam[0], gam[1]); st2(sl + O_TAB + 2, gam[2], gam[3]);
@@ -379,11 +384,11 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 }
             }
             // terminal cost-to-go: none (no *_e cost or bound in mpcPathTracking.py)
-            if (lane < 48) xa[X_P + lane] = 0.0;
+            if (tid < 48) xa[X_P + tid] = 0.0;
             w.sync();
 
-            // ---- factor sweep, k = N-1 .. 0 (augmented Riccati recursion)
-            {
+            // ---- factor sweep, k = N-1 .. 0 (augmented Riccati recursion), first wave only
+            if (w.sweep_wave()) {
                 // per-lane LDS pointers of this sweep, recomputed here (a few dozen integer ops per
                 // interior-point iteration) instead of living in ~45 registers through the whole solve;
                 // strides are in doubles per stage: ST for per-stage data, 0 for constants
@@ -463,7 +468,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     accA = fma(r23.x, t2, accA);    accB = fma(r45.y, b2, accB);
                     accA = fma(r45.x, b01.y, accA);
                     *pMw = accA + accB;
-                    w.sync();
+                    w.wsync();
                     // phase 2: Ht[i][j] = cost[i][j] + BAt[0..5][i] . Mt[0..5][j]
                     const D2 m01 = ld2(pMr), m23 = ld2(pMr + 2), m45 = ld2(pMr + 4);
                     w.sched_fence();
@@ -472,7 +477,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     HvA = fma(v01.y, m45.x, HvA); HvB = fma(v2, m45.y, HvB);
                     const double Hv = HvA + HvB;
                     *pHw = Hv;
-                    w.sync();
+                    w.wsync();
                     // phase 3: eliminate the inputs
                     const D2 hu0 = ld2(xa + X_HU), hu1 = ld2(xa + X_HU + 2);   // (H00,-), (H01,H11)
                     const D2 hj = ld2(pHj), hi = ld2(pHi);
@@ -485,7 +490,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     *pPw1 = Pn;
                     *pPw2 = Pn;
                     st2(kw, K0, K1);
-                    w.sync();
+                    w.wsync();
                     tj -= sTopJ; bj -= sBotJ; ti -= sTopI; tb -= sTab; kw -= sKw;
                 }
             }
@@ -496,7 +501,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
             double smu = 0.0, csc = 0.0, mu_aff = 0.0;
 #pragma unroll 1
             for (int pass = 0; pass < 2; ++pass) {
-                if (pass == 1) {
+                if (w.sweep_wave() && pass == 1) {
                     // backward vector sweep (corrector right-hand side, homogeneous dynamics): lane vl
                     // owns z component vl, the recursion vector p is wave-uniform (re-gathered with
                     // readlane: no LDS round trip on the serial path)
@@ -537,11 +542,11 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                         p3 = w.readlane(res, 5); p4 = w.readlane(res, 6); p5 = w.readlane(res, 7);
                         tv -= sTopV; dg -= sDgV; ab -= ST; kfw -= sKfw;
                     }
-                    w.sync();
+                    w.wsync();
                 }
                 // forward sweep: lane vl computes row vr of dx+ and input (vl & 1); z_k is stored in
                 // slot k-1 (its r_b has been consumed), dx is wave-uniform
-                {
+                if (w.sweep_wave()) {
                     const double rbs = pass == 0 ? 1.0 : 0.0;
                     const int fl = w.opaque(lane);
                     const int vl = fl & 7;
@@ -583,8 +588,8 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
 #pragma unroll
                         for (int m = 0; m < 6; ++m) ct[O_D + 2 + m] = 0.0;
                     }
-                    w.sync();
                 }
+                w.sync();
                 // ---- stage layout: pick up the direction of this node (slot node-1 holds z_node)
                 double dzl[8];
                 {
@@ -632,7 +637,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     csc = fmin(1.0, 4.0 * a_aff);
                     // (the pick-up reads above are ordered before these stores by the reductions)
                     if (act) {
-                        double *sl = stg + lane * ST + O_D;
+                        double *sl = stg + tid * ST + O_D;
                         double dG[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
@@ -693,7 +698,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
         ub_[1] += z[1];
 #pragma unroll
         for (int m = 0; m < 6; ++m) xb[m] += z[2 + m];
-        if (lane == 0) {
+        if (tid == 0) {
 #pragma unroll
             for (int m = 0; m < 6; ++m) xb[m] = io.x0[m];
         }
@@ -711,7 +716,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
 
     // ---------------------------------------------------------------- write back
     if (has_node) {
-        double *t = io.traj + lane * 8;
+        double *t = io.traj + tid * 8;
 #pragma unroll
         for (int m = 0; m < 6; ++m) t[m] = xb[m];
         t[6] = act ? ub_[0] : 0.0;
@@ -719,7 +724,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
     }
     const double u00 = w.readlane(ub_[0], 0), u01 = w.readlane(ub_[1], 0);
     const double d1 = w.readlane(xb[4], 1), t1 = w.readlane(xb[5], 1);
-    if (lane == 0) {
+    if (tid == 0) {
         io.ctrl[0] = u00; io.ctrl[1] = u01; io.ctrl[2] = d1; io.ctrl[3] = t1;
         io.ctrl[4] = cost_out;
         io.ctrl[5] = (double)(status + 16 * total_ipm);

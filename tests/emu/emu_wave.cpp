@@ -1,9 +1,10 @@
-// emu_wave.cpp -- CPU lane emulator for mpc_local_planner_amd/csrc/nmpc_wave_solver.h.
-// TEST INFRASTRUCTURE ONLY (built by tests/emu/Makefile, loaded by tests/test_emu_*.py).
-// It runs the *same source* the gfx950 kernel runs, with the 64 lanes of a wave as 64
-// ucontext coroutines that switch round-robin at every wave sync / cross-lane op, so the
-// lane mappings, LDS layout and exchange protocol can be checked against the oracle on a
-// machine without a GPU.  The product never links this file.
+// emu_wave.cpp -- CPU thread emulator for mpc_local_planner_amd/csrc/nmpc_wave_solver.h.
+// TEST INFRASTRUCTURE ONLY (built by tests/emu/Makefile, loaded by tests/emu_binding.py).
+// It runs the *same source* the gfx950 kernel runs, with the 64 (N <= 63) or 128 threads of an
+// instance's workgroup as ucontext coroutines.  Every wave policy call that exchanges data is a
+// real barrier here (wave-wide or workgroup-wide, as on the GPU), so a missing or misplaced
+// exchange point shows up as a wrong result or a deadlock report instead of passing by luck of
+// the lock-step hardware.  The product never links this file.
 #include <ucontext.h>
 
 #include <cstdio>
@@ -17,24 +18,68 @@
 namespace {
 
 constexpr int WAVE = 64;
+constexpr int MAXT = 128;
 constexpr size_t STACK = 512 * 1024;
+
+struct Barrier {
+    int count = 0;
+    long gen = 0;
+};
 
 struct Sched {
     ucontext_t main_ctx;
-    ucontext_t ctx[WAVE];
+    ucontext_t ctx[MAXT];
     std::vector<char> stacks;
+    int nt = WAVE;              // threads of the instance
+    bool done[MAXT];
     double *lds = nullptr;
-    double tmp[WAVE];
-    long nsync[WAVE];
+    double tmp[MAXT];
+    Barrier wg, wave[MAXT / WAVE];
+    long spins = 0;
+    bool deadlock = false;
     const nmpcw::Problem *pb = nullptr;
     const nmpcw::InstanceIO *io = nullptr;
 };
 
 Sched *g_s = nullptr;
 
+void yield_from(int t)
+{
+    // round robin over the threads that have not finished
+    Sched &s = *g_s;
+    for (int i = 1; i <= s.nt; ++i) {
+        const int n = (t + i) % s.nt;
+        if (n == t) return;     // nobody else can run
+        if (!s.done[n]) {
+            swapcontext(&s.ctx[t], &s.ctx[n]);
+            return;
+        }
+    }
+}
+
+void barrier(Barrier &b, int nthreads, int t)
+{
+    const long gen = b.gen;
+    if (++b.count == nthreads) {
+        b.count = 0;
+        ++b.gen;
+        g_s->spins = 0;
+    }
+    // always give the others a turn: exchange points double as scheduling points
+    do {
+        yield_from(t);
+        if (b.gen == gen && ++g_s->spins > 50000000L) {
+            g_s->deadlock = true;
+            setcontext(&g_s->main_ctx);
+        }
+    } while (b.gen == gen);
+}
+
 struct EmuWave {
-    int lane_;
-    int lane() const { return lane_; }
+    int tid_;
+    int tid() const { return tid_; }
+    int lane() const { return tid_ & (WAVE - 1); }
+    bool sweep_wave() const { return tid_ < WAVE; }
     double *lds() { return g_s->lds; }
     int opaque(int v) { return v; }
     void sched_fence() {}
@@ -45,60 +90,61 @@ struct EmuWave {
         for (int c = 0; c < 6; ++c) rr[c] = rw[4 * c];
         *rbv = *rbp;
     }
-    void sync()
-    {
-        g_s->nsync[lane_]++;
-        swapcontext(&g_s->ctx[lane_], &g_s->ctx[(lane_ + 1) % WAVE]);
-    }
-    void sync_lockstep() { sync(); }
+    void sync() { barrier(g_s->wg, g_s->nt, tid_); }
+    void wsync() { barrier(g_s->wave[tid_ / WAVE], WAVE, tid_); }
+    void sync_lockstep() { wsync(); }
     double rcp(double x) { return 1.0 / x; }
-    double readlane(double v, int src)
+    double readlane(double v, int src)        // within the calling wave
     {
-        g_s->tmp[lane_] = v;
-        sync();
-        const double r = g_s->tmp[src];
-        sync();
+        g_s->tmp[tid_] = v;
+        wsync();
+        const double r = g_s->tmp[(tid_ / WAVE) * WAVE + src];
+        wsync();
         return r;
     }
-    double shfl_down1(double v)
+    double shfl_down1(double v)                // across the whole instance
     {
-        g_s->tmp[lane_] = v;
+        g_s->tmp[tid_] = v;
         sync();
-        const double r = g_s->tmp[lane_ + 1 < WAVE ? lane_ + 1 : lane_];
+        const double r = g_s->tmp[tid_ + 1 < g_s->nt ? tid_ + 1 : tid_];
         sync();
         return r;
     }
     double sum(double v)
     {
-        g_s->tmp[lane_] = v;
+        g_s->tmp[tid_] = v;
         sync();
-        double t[WAVE];
+        double t[MAXT];
         memcpy(t, g_s->tmp, sizeof(t));
-        for (int o = 32; o >= 1; o >>= 1)   // a butterfly like the GPU policy (association differs: round-off only)
-            for (int l = 0; l < WAVE; ++l)
+        const int nt = g_s->nt;
+        // a butterfly like the GPU policy (the association differs: round-off only)
+        for (int o = nt / 2; o >= 1; o >>= 1)
+            for (int l = 0; l < nt; ++l)
                 if ((l & o) == 0) { const double a = t[l] + t[l | o]; t[l] = a; t[l | o] = a; }
         sync();
-        return t[lane_];
+        return t[tid_];
     }
     double max(double v)
     {
-        g_s->tmp[lane_] = v;
+        g_s->tmp[tid_] = v;
         sync();
         double r = g_s->tmp[0];
-        for (int l = 1; l < WAVE; ++l) r = g_s->tmp[l] > r ? g_s->tmp[l] : r;
+        for (int l = 1; l < g_s->nt; ++l) r = g_s->tmp[l] > r ? g_s->tmp[l] : r;
         sync();
         return r;
     }
 };
 
-void lane_main(int lane)
+void thread_main(int t)
 {
-    EmuWave w{lane};
+    EmuWave w{t};
     nmpcw::solve_instance(w, *g_s->pb, *g_s->io);
-    if (lane + 1 < WAVE)
-        setcontext(&g_s->ctx[lane + 1]);
-    else
-        setcontext(&g_s->main_ctx);
+    g_s->done[t] = true;
+    for (int i = 1; i < g_s->nt; ++i) {
+        const int n = (t + i) % g_s->nt;
+        if (!g_s->done[n]) setcontext(&g_s->ctx[n]);
+    }
+    setcontext(&g_s->main_ctx);
 }
 
 }  // namespace
@@ -110,15 +156,19 @@ extern "C" int emu_solve_batch(int N, double dt, double wheelbase, int ipm_max_i
                                double *ctrl, int *status, int *iters, int *sqp_iters, double *cost,
                                int cold)
 {
+    if (N < 1 || N > 127) return 2;
     nmpcw::Problem pb;
     pb.N = N; pb.dt = dt; pb.inv_wheelbase = 1.0 / wheelbase;
     pb.ipm_max_iter = ipm_max_iter; pb.mu0 = mu0; pb.thr0 = thr0; pb.tau = tau;
-    pb.tol_mu = tol_mu; pb.tol_lin = tol_lin; pb.tol_comp = tol_comp; pb.sqp_max_iter = sqp_max_iter; pb.sqp_tol = sqp_tol;
+    pb.tol_mu = tol_mu; pb.tol_lin = tol_lin; pb.tol_comp = tol_comp;
+    pb.sqp_max_iter = sqp_max_iter; pb.sqp_tol = sqp_tol;
     Sched s;
     g_s = &s;
-    s.stacks.resize(STACK * WAVE);
-    std::vector<double> lds((size_t)nmpcw::lds_doubles(N));
-    s.lds = lds.data();
+    s.nt = WAVE * nmpcw::waves_per_instance(N);
+    s.stacks.resize(STACK * s.nt);
+    std::vector<double> lds((size_t)nmpcw::lds_doubles(N) + 2);
+    // 16-byte aligned base, as on the GPU (the body uses paired loads)
+    s.lds = lds.data() + ((reinterpret_cast<size_t>(lds.data()) & 15) ? 1 : 0);
     s.pb = &pb;
     int rc = 0;
     for (int b = 0; b < B; ++b) {
@@ -128,18 +178,26 @@ extern "C" int emu_solve_batch(int N, double dt, double wheelbase, int ipm_max_i
         io.ctrl = ctrl + (size_t)b * 6; io.status = status + b; io.iters = iters + b;
         io.sqp_iters = sqp_iters + b; io.cost = cost + b; io.cold = cold;
         s.io = &io;
-        for (size_t i = 0; i < lds.size(); ++i) lds[i] = -1e300 * 1e10;   // poison (-inf)
-        for (int l = 0; l < WAVE; ++l) {
-            s.nsync[l] = 0;
-            getcontext(&s.ctx[l]);
-            s.ctx[l].uc_stack.ss_sp = s.stacks.data() + STACK * l;
-            s.ctx[l].uc_stack.ss_size = STACK;
-            s.ctx[l].uc_link = nullptr;
-            makecontext(&s.ctx[l], (void (*)())lane_main, 1, l);
+        for (size_t i = 0; i < (size_t)nmpcw::lds_doubles(N); ++i) s.lds[i] = -1e300 * 1e10;   // poison (-inf)
+        s.wg = Barrier();
+        for (auto &wb : s.wave) wb = Barrier();
+        s.spins = 0;
+        for (int t = 0; t < s.nt; ++t) {
+            s.done[t] = false;
+            getcontext(&s.ctx[t]);
+            s.ctx[t].uc_stack.ss_sp = s.stacks.data() + STACK * t;
+            s.ctx[t].uc_stack.ss_size = STACK;
+            s.ctx[t].uc_link = nullptr;
+            makecontext(&s.ctx[t], (void (*)())thread_main, 1, t);
         }
         swapcontext(&s.main_ctx, &s.ctx[0]);
-        for (int l = 1; l < WAVE; ++l)
-            if (s.nsync[l] != s.nsync[0]) { fprintf(stderr, "emu: divergent sync count lane %d\n", l); rc = 1; }
+        if (s.deadlock) {
+            fprintf(stderr, "emu: threads never met at an exchange point (instance %d)\n", b);
+            rc = 1;
+            break;
+        }
+        for (int t = 0; t < s.nt; ++t)
+            if (!s.done[t]) { fprintf(stderr, "emu: thread %d did not finish\n", t); rc = 1; }
     }
     g_s = nullptr;
     return rc;

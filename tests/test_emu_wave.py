@@ -17,9 +17,9 @@ def _err(g, xo, uo):
 
 
 @pytest.mark.parametrize("N,gen", [(40, sc.config2), (10, sc.config2), (63, sc.config2), (1, sc.config2),
-                                   (2, sc.config2), (40, sc.config4)])
+                                   (2, sc.config2), (40, sc.config4), (64, sc.config2), (100, sc.config4)])
 def test_emulated_wave_matches_oracle_cold_and_warm(N, gen):
-    B = 12
+    B = 12 if N <= 63 else 3            # two emulated waves per instance beyond N = 63
     cfg = orc.default_config(N, 0.35)
     x0, p = gen(B)
     g = emu.solve_batch(cfg, x0, p)

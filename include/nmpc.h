@@ -109,6 +109,35 @@ int nmpc_get(nmpc_handle *h, int B, double *x, double *u, int32_t *status, doubl
  * (what src/RosMpc.cpp:82-86 sends to the car), cost, status + 16*ipm_iters. */
 int nmpc_get_controls(nmpc_handle *h, int B, double *ctrl);
 
+/* ---- path front-end and closed loop (the caller side of the solve: SURVEY.md 8(f) rows f1, f2) ----
+ *
+ * Replaces PathTrackingSys's track (src/PathTrackingSys.cpp:13, PathTrackingSys.h setTrack): xy[n][2]
+ * in the map frame, shared by all instances of the handle.  n >= 5. */
+int nmpc_set_track(nmpc_handle *h, const double *xy, int n_points);
+
+/* Replaces PathTrackingSys::calcCoeffs + the frame transform of PathTrackingSys::solve(state, pitch,
+ * vRef) (src/PathTrackingSys.cpp:17-25,63-136) for B instances: world_state[B][6] =
+ * x,y,psi,vel,delta,throttle in the map frame, pitch_vref[B][2].  Leaves the solver-frame state
+ * (0,0,rotation,vel,delta,throttle) and the parameters (c0..c3,pitch,vRef) in the handle's device
+ * input buffers, i.e. the next nmpc_solve uses them. */
+int nmpc_frontend(nmpc_handle *h, const double *world_state, const double *pitch_vref, int B);
+
+/* What the front-end produced: x0_solver[B][6], params[B][6], rotation[B] (any may be NULL). */
+int nmpc_get_frontend(nmpc_handle *h, int B, double *x0_solver, double *params, double *rotation);
+
+/* Replaces the un-rotation loop of PathTrackingSys::solve (src/PathTrackingSys.cpp:27-41): predicted
+ * positions of the last solve in the map frame, xy[B][N+1][2] (psi is not un-rotated there either). */
+int nmpc_get_world_path(nmpc_handle *h, int B, double *xy);
+
+/* Closed loop on the device, `steps` control ticks of: front-end -> one SQP-RTI iteration (warm
+ * start, no shift) -> actuation rule of src/RosMpc.cpp:81-90 (delta <- x[1].delta, throttle <-
+ * x[1].throttle) -> plant (RK4 of x,y,psi,vel over dt_plant seconds with the commands held;
+ * src/main.cpp:14 runs the loop at 30 Hz).  world_state[B][6] in/out, pitch_vref[B][2].
+ * trace (optional) receives the world states after every tick, [steps][B][6]; n_failed (optional)
+ * the number of (instance, tick) solves with status != 0 (asking for it adds a host sync per tick). */
+int nmpc_closed_loop(nmpc_handle *h, int B, int steps, double dt_plant, double steering_ratio,
+                     double *world_state, const double *pitch_vref, double *trace, int32_t *n_failed);
+
 /* Device-side views for zero-copy consumers (RCCL all-gather of the control records,
  * timing with HIP events).  which: 0 control records [cap][6], 1 iterate [cap][N+1][8]
  * (X,Y,psi,v,delta,thr,u0,u1 per node), 2 status int32[cap]. */

@@ -33,6 +33,7 @@ EXPORTS = [
     "nmpc_solve",
     "nmpc_sync", "nmpc_get", "nmpc_get_controls", "nmpc_device_ptr", "nmpc_stream",
     "nmpc_capacity", "nmpc_horizon", "nmpc_last_error",
+    "nmpc_set_track", "nmpc_frontend", "nmpc_get_frontend", "nmpc_get_world_path", "nmpc_closed_loop",
 ]
 
 _lib = None
@@ -74,6 +75,11 @@ def lib():
     l.nmpc_capacity.argtypes = [vp]
     l.nmpc_horizon.argtypes = [vp]
     l.nmpc_last_error.restype = C.c_char_p
+    l.nmpc_set_track.argtypes = [vp, dp, C.c_int]
+    l.nmpc_frontend.argtypes = [vp, dp, dp, C.c_int]
+    l.nmpc_get_frontend.argtypes = [vp, C.c_int, dp, dp, dp]
+    l.nmpc_get_world_path.argtypes = [vp, C.c_int, dp]
+    l.nmpc_closed_loop.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double, dp, dp, dp, ip]
     _lib = l
     return l
 
@@ -190,6 +196,41 @@ class BatchSolver:
         c = np.zeros((B, 6))
         check(lib().nmpc_get_controls(self._h, B, _dp(c)), "nmpc_get_controls")
         return c
+
+    # ---- path front-end / closed loop
+    def set_track(self, xy):
+        xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+        check(lib().nmpc_set_track(self._h, _dp(xy), xy.shape[0]), "nmpc_set_track")
+
+    def frontend(self, world_state, pitch_vref):
+        ws = np.ascontiguousarray(world_state, dtype=np.float64).reshape(-1, 6)
+        pv = np.ascontiguousarray(pitch_vref, dtype=np.float64).reshape(-1, 2)
+        assert ws.shape[0] == pv.shape[0]
+        check(lib().nmpc_frontend(self._h, _dp(ws), _dp(pv), ws.shape[0]), "nmpc_frontend")
+
+    def get_frontend(self, B=None):
+        B = B or self.capacity
+        x0, p, rot = np.zeros((B, 6)), np.zeros((B, 6)), np.zeros(B)
+        check(lib().nmpc_get_frontend(self._h, B, _dp(x0), _dp(p), _dp(rot)), "nmpc_get_frontend")
+        return x0, p, rot
+
+    def get_world_path(self, B=None):
+        B = B or self.capacity
+        xy = np.zeros((B, self.N + 1, 2))
+        check(lib().nmpc_get_world_path(self._h, B, _dp(xy)), "nmpc_get_world_path")
+        return xy
+
+    def closed_loop(self, world_state, pitch_vref, steps, dt_plant=1.0 / 30.0, steering_ratio=1.0,
+                    trace=False, count_failures=False):
+        ws = np.array(world_state, dtype=np.float64).reshape(-1, 6)
+        pv = np.ascontiguousarray(pitch_vref, dtype=np.float64).reshape(-1, 2)
+        B = ws.shape[0]
+        tr = np.zeros((steps, B, 6)) if trace else None
+        nf = C.c_int32(0)
+        check(lib().nmpc_closed_loop(self._h, B, steps, dt_plant, steering_ratio, _dp(ws), _dp(pv),
+                                     _dp(tr) if trace else None, C.byref(nf) if count_failures else None),
+              "nmpc_closed_loop")
+        return ws, tr, nf.value
 
     def device_ptr(self, which):
         return lib().nmpc_device_ptr(self._h, which)

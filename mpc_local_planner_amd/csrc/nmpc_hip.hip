@@ -10,6 +10,7 @@
 
 #define NMPC_DEV __device__ __forceinline__
 #include "nmpc_wave_solver.h"
+#include "nmpc_frontend.h"
 
 #include "../../include/nmpc.h"
 
@@ -185,6 +186,50 @@ __global__ void __launch_bounds__(64 * NW, 2) nmpc_solve_kernel(KernelArgs a)
     if (threadIdx.x == 0) a.reset[inst] = (*io.status != 0 && *io.status != 2) ? 1 : 0;
 }
 
+// ---- path front-end, un-rotation and closed-loop plant: one thread per instance
+__global__ void nmpc_frontend_kernel(const double *track, int T, const double *ws, const double *pv, int B,
+                                     double *x0s, double *par, double *rot)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    double w[6], x0[6], p[6], r;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) w[m] = ws[(size_t)i * 6 + m];
+    nmpcf::frontend(track, T, w, pv[(size_t)i * 2], pv[(size_t)i * 2 + 1], x0, p, &r);
+#pragma unroll
+    for (int m = 0; m < 6; ++m) { x0s[(size_t)i * 6 + m] = x0[m]; par[(size_t)i * 6 + m] = p[m]; }
+    rot[i] = r;
+}
+
+__global__ void nmpc_unrotate_kernel(const double *traj, const double *ws, const double *rot, int B, int N1,
+                                     double *xy)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * N1) return;
+    const int i = t / N1;
+    double w[6];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) w[m] = ws[(size_t)i * 6 + m];
+    double wx, wy;
+    nmpcf::unrotate(w, rot[i], traj[(size_t)t * 8], traj[(size_t)t * 8 + 1], &wx, &wy);
+    xy[(size_t)t * 2] = wx;
+    xy[(size_t)t * 2 + 1] = wy;
+}
+
+__global__ void nmpc_plant_kernel(double *ws, const double *pv, const double *ctrl, int B, double dtp,
+                                  double inv_wheelbase, double steering_ratio)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    double w[6];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) w[m] = ws[(size_t)i * 6 + m];
+    nmpcf::plant_step(w, ctrl[(size_t)i * 6 + 2], ctrl[(size_t)i * 6 + 3], pv[(size_t)i * 2], dtp, inv_wheelbase,
+                      steering_ratio);
+#pragma unroll
+    for (int m = 0; m < 6; ++m) ws[(size_t)i * 6 + m] = w[m];
+}
+
 __global__ void nmpc_fill_rows_kernel(double *dst, int rows, int width, const double *vals8)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -225,6 +270,9 @@ struct nmpc_handle {
     unsigned char *d_reset, *d_mask;
     const double *in_x0, *in_p;   // what the kernel reads (own buffers or caller's device buffers)
     std::vector<double> h_traj;
+    // path front-end / closed loop (allocated by nmpc_set_track)
+    double *d_track = nullptr, *d_ws = nullptr, *d_pv = nullptr, *d_rot = nullptr, *d_xy = nullptr;
+    int n_track = 0;
 };
 
 extern "C" {
@@ -337,7 +385,8 @@ int nmpc_destroy(nmpc_handle *h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_x0, h->d_p, h->d_W, h->d_bnd, h->d_traj, h->d_ctrl, h->d_cost, h->d_tmp,
-                    h->d_status, h->d_iters, h->d_sqp, h->d_reset, h->d_mask};
+                    h->d_status, h->d_iters, h->d_sqp, h->d_reset, h->d_mask,
+                    h->d_track, h->d_ws, h->d_pv, h->d_rot, h->d_xy};
     int rc = NMPC_OK;
     for (void *p : ptrs)
         if (p && !hip_ok(hipFree(p), "hipFree")) rc = NMPC_EHIP;
@@ -500,6 +549,111 @@ int nmpc_get_controls(nmpc_handle *h, int B, double *ctrl)
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemcpyAsync(ctrl, h->d_ctrl, sizeof(double) * (size_t)B * 6, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return NMPC_OK;
+}
+
+// ---- path front-end and closed loop
+
+int nmpc_set_track(nmpc_handle *h, const double *xy, int n_points)
+{
+    if (!h || !xy || n_points < 5) return NMPC_EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t cap = (size_t)h->capacity, N1 = (size_t)h->cfg.N + 1;
+    if (h->d_track) { HIP_TRY(hipFree(h->d_track)); h->d_track = nullptr; }
+    HIP_TRY(hipMalloc((void **)&h->d_track, sizeof(double) * 2 * (size_t)n_points));
+    if (!h->d_ws) {
+        HIP_TRY(hipMalloc((void **)&h->d_ws, sizeof(double) * 6 * cap));
+        HIP_TRY(hipMalloc((void **)&h->d_pv, sizeof(double) * 2 * cap));
+        HIP_TRY(hipMalloc((void **)&h->d_rot, sizeof(double) * cap));
+        HIP_TRY(hipMalloc((void **)&h->d_xy, sizeof(double) * 2 * cap * N1));
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_track, xy, sizeof(double) * 2 * (size_t)n_points, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->n_track = n_points;
+    return NMPC_OK;
+}
+
+static int launch_frontend(nmpc_handle *h, int B)
+{
+    hipLaunchKernelGGL(nmpc_frontend_kernel, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->d_track, h->n_track,
+                       h->d_ws, h->d_pv, B, h->d_x0, h->d_p, h->d_rot);
+    HIP_TRY(hipGetLastError());
+    h->in_x0 = h->d_x0;
+    h->in_p = h->d_p;
+    return NMPC_OK;
+}
+
+int nmpc_frontend(nmpc_handle *h, const double *world_state, const double *pitch_vref, int B)
+{
+    if (!h || !world_state || !pitch_vref || B <= 0 || B > h->capacity || !h->d_track) return NMPC_EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->d_ws, world_state, sizeof(double) * 6 * (size_t)B, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_pv, pitch_vref, sizeof(double) * 2 * (size_t)B, hipMemcpyHostToDevice, h->stream));
+    const int rc = launch_frontend(h, B);
+    if (rc != NMPC_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));   // the caller's buffers may be reused
+    return NMPC_OK;
+}
+
+int nmpc_get_frontend(nmpc_handle *h, int B, double *x0_solver, double *params, double *rotation)
+{
+    if (!h || B <= 0 || B > h->capacity || !h->d_track) return NMPC_EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    if (x0_solver) HIP_TRY(hipMemcpyAsync(x0_solver, h->d_x0, sizeof(double) * 6 * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    if (params) HIP_TRY(hipMemcpyAsync(params, h->d_p, sizeof(double) * 6 * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    if (rotation) HIP_TRY(hipMemcpyAsync(rotation, h->d_rot, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return NMPC_OK;
+}
+
+int nmpc_get_world_path(nmpc_handle *h, int B, double *xy)
+{
+    if (!h || !xy || B <= 0 || B > h->capacity || !h->d_track) return NMPC_EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    const int N1 = h->cfg.N + 1;
+    hipLaunchKernelGGL(nmpc_unrotate_kernel, dim3((B * N1 + 255) / 256), dim3(256), 0, h->stream, h->d_traj, h->d_ws,
+                       h->d_rot, B, N1, h->d_xy);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(xy, h->d_xy, sizeof(double) * 2 * (size_t)B * N1, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return NMPC_OK;
+}
+
+int nmpc_closed_loop(nmpc_handle *h, int B, int steps, double dt_plant, double steering_ratio,
+                     double *world_state, const double *pitch_vref, double *trace, int32_t *n_failed)
+{
+    if (!h || !world_state || !pitch_vref || B <= 0 || B > h->capacity || steps < 1 || !h->d_track ||
+        !(dt_plant > 0.0) || !(steering_ratio != 0.0))
+        return NMPC_EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->d_ws, world_state, sizeof(double) * 6 * (size_t)B, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_pv, pitch_vref, sizeof(double) * 2 * (size_t)B, hipMemcpyHostToDevice, h->stream));
+    int failed = 0;
+    std::vector<int32_t> st;
+    for (int s = 0; s < steps; ++s) {
+        // front-end -> one SQP-RTI iteration (warm start, no shift) -> actuation + plant, all on the
+        // handle's stream; no host round trip unless the caller asked for a trace
+        int rc = launch_frontend(h, B);
+        if (rc != NMPC_OK) return rc;
+        rc = nmpc_solve(h, B, NMPC_MODE_RTI, 1, 0.0);
+        if (rc != NMPC_OK) return rc;
+        hipLaunchKernelGGL(nmpc_plant_kernel, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->d_ws, h->d_pv, h->d_ctrl,
+                           B, dt_plant, 1.0 / h->cfg.wheelbase, steering_ratio);
+        HIP_TRY(hipGetLastError());
+        if (trace)
+            HIP_TRY(hipMemcpyAsync(trace + (size_t)s * B * 6, h->d_ws, sizeof(double) * 6 * (size_t)B,
+                                   hipMemcpyDeviceToHost, h->stream));
+        if (n_failed) {
+            st.resize((size_t)B);
+            HIP_TRY(hipMemcpyAsync(st.data(), h->d_status, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            for (int32_t v : st) failed += v != 0;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(world_state, h->d_ws, sizeof(double) * 6 * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (n_failed) *n_failed = failed;
     return NMPC_OK;
 }
 

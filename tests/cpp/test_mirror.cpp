@@ -6,7 +6,9 @@
 #include <fstream>
 #include <vector>
 
-#include "mpc_local_planner_amd/AcadosSolver.hpp"
+#include <cmath>
+
+#include "mpc_local_planner_amd/PathTrackingSys.hpp"
 
 int main(int argc, char **argv) {
     if (argc < 3) return 2;
@@ -41,6 +43,21 @@ int main(int argc, char **argv) {
                    o.x.throttle, o.u.deltaDot, o.u.throttleDot);
         printf("\n");
         if (r.mpcHorizon.size() != (size_t)N || r.u0.deltaDot != r.mpcHorizon[0].u.deltaDot) return 3;
+    }
+    // PathTrackingSys on an ellipse-like track: state on the track -> world-frame horizon
+    {
+        std::vector<mpc::Point> track;
+        for (int i = 0; i < 400; ++i) {
+            const double th = 2 * M_PI * i / 400.0;
+            track.emplace_back(40 * cos(th), 20 * sin(th) + 20 / 1.2 * sin(3 * th));
+        }
+        mpc::PathTrackingSys sys{track, N};
+        const mpc::State car{41, 0, M_PI / 2, 5, 0, 0};          // tests/testMpc.h:13
+        auto r = sys.solve(car, 0.0, 5.0);
+        printf("pts %d %.17g", (int)r.success, sys.lastRotation());
+        for (auto &o : r.mpcHorizon) printf(" %.17g %.17g", o.x.x, o.x.y);
+        printf("\n");
+        if (r.mpcHorizon.size() != (size_t)N) return 5;
     }
     // error behaviour: an impossible horizon throws from the constructor (AcadosPathTracking.cpp:42-47)
     try {

@@ -14,8 +14,9 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        src = [os.path.join(_HERE, "emu", "emu_wave.cpp"),
-               os.path.join(_HERE, "..", "mpc_local_planner_amd", "csrc", "nmpc_wave_solver.h")]
+        csrc = os.path.join(_HERE, "..", "mpc_local_planner_amd", "csrc")
+        src = [os.path.join(_HERE, "emu", "emu_wave.cpp"), os.path.join(_HERE, "emu", "emu_frontend.cpp"),
+               os.path.join(csrc, "nmpc_wave_solver.h"), os.path.join(csrc, "nmpc_frontend.h")]
         if not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src):
             subprocess.check_call(["make", "-C", os.path.join(_HERE, "emu"), "-s", "-B"])
         _lib = C.CDLL(_LIB)
@@ -23,7 +24,29 @@ def lib():
         d, i = C.c_double, C.c_int
         _lib.emu_solve_batch.argtypes = [i, d, d, i, d, d, d, d, d, d, i, d, i,
                                          dp, dp, dp, dp, dp, dp, ip, ip, ip, dp, i]
+        _lib.emu_frontend.argtypes = [dp, i, dp, dp, i, dp, dp, dp]
+        _lib.emu_plant_step.argtypes = [dp, d, d, d, d, d, d]
+        _lib.emu_unrotate.argtypes = [dp, d, d, d, dp]
     return _lib
+
+
+def frontend(track, ws, pv):
+    """nmpc_frontend.h compiled for the CPU: solver-frame state, parameters, rotation."""
+    track = np.ascontiguousarray(track, dtype=np.float64)
+    ws = np.ascontiguousarray(ws, dtype=np.float64).reshape(-1, 6)
+    pv = np.ascontiguousarray(pv, dtype=np.float64).reshape(-1, 2)
+    B = ws.shape[0]
+    x0s, par, rot = np.zeros((B, 6)), np.zeros((B, 6)), np.zeros(B)
+    dd = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    lib().emu_frontend(dd(track), track.shape[0], dd(ws), dd(pv), B, dd(x0s), dd(par), dd(rot))
+    return x0s, par, rot
+
+
+def plant_step(ws, delta_cmd, thr_cmd, pitch, dtp, wheelbase=2.65, steering_ratio=1.0):
+    ws = np.array(ws, dtype=np.float64)
+    lib().emu_plant_step(ws.ctypes.data_as(C.POINTER(C.c_double)), delta_cmd, thr_cmd, pitch, dtp,
+                         1.0 / wheelbase, steering_ratio)
+    return ws
 
 
 def solve_batch(cfg, x0, p, W=None, bnd=None, traj=None, cold=True, sqp_max_iter=1, sqp_tol=1e-6):

@@ -40,6 +40,12 @@ def test_cpp_mirror_single_and_batch(tmp_path):
             assert np.abs(h[:, :6] - xo[b, :N]).max() <= 1e-6 * s
             assert np.abs(h[:, 6:] - uo[b]).max() <= 1e-6 * s
             nb += 1
+        elif t[0] == "pts":
+            # PathTrackingSys::solve(state, pitch, vRef): starts at the car, moves along the track
+            assert t[1] == "1"
+            pts = np.array(t[3:], dtype=float).reshape(N, 2)
+            assert np.abs(pts[0] - [41.0, 0.0]).max() < 1e-9
+            assert pts[5, 1] > 3.0 and abs(pts[5, 0] - 40.0) < 3.0
         elif t[0] == "single":
             assert t[2] == "1"
             single.append(np.array(t[4:], dtype=float).reshape(N, 8))

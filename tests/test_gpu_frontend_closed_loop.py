@@ -1,0 +1,132 @@
+"""GPU: path front-end (f1), BASELINE config 1 and the closed-loop driver (f2 / config 5) through
+the C ABI, against the oracle."""
+import math
+
+import numpy as np
+import pytest
+
+from mpc_local_planner_amd import capi
+from oracle import oracle as orc
+from test_frontend_emu import world_states
+
+pytestmark = pytest.mark.gpu
+
+
+def _ocfg(N):
+    return orc.config_like(capi.default_config(N, 0.35))
+
+
+def test_frontend_kernel_matches_oracle():
+    t, ws, pv = world_states(512, seed=11)
+    s = capi.BatchSolver(N=40, dt=0.35, capacity=512)
+    s.set_track(t)
+    s.frontend(ws, pv)
+    x0s, par, rot = s.get_frontend()
+    for i in range(ws.shape[0]):
+        st, en = orc.track_section(t, ws[i, 0], ws[i, 1])
+        if en - st == 4:
+            continue
+        r, c = orc.calc_coeffs(t, ws[i])
+        assert rot[i] == r, (i, rot[i], r)
+        assert np.abs(par[i, :4] - c).max() <= 1e-9 * max(1.0, np.abs(c).max())
+        assert np.array_equal(x0s[i], [0.0, 0.0, r, ws[i, 3], ws[i, 4], ws[i, 5]])
+        assert np.array_equal(par[i, 4:], pv[i])
+    s.close()
+
+
+@pytest.mark.parametrize("N", [30, 40])
+def test_config1_single_solve_full_chain(N):
+    """tests/testMpc.h:13 initial state on util::getTestTrack: front-end -> cold guess -> one RTI
+    -> un-rotation (PathTrackingSys::solve(state, pitch, vRef), src/PathTrackingSys.cpp:17-56)."""
+    t = orc.test_track()
+    ws = np.array([[41.0, 0.0, math.pi / 2, 5.0, 0.0, 0.0]])
+    pv = np.array([[0.0, 5.0]])
+    s = capi.BatchSolver(N=N, dt=0.35, capacity=1)
+    s.set_track(t)
+    s.frontend(ws, pv)
+    s.solve(1)
+    g = s.get(1)
+    xy = s.get_world_path(1)
+    rot, c = orc.calc_coeffs(t, ws[0])
+    xs = np.array([0.0, 0.0, rot, 5.0, 0.0, 0.0])
+    p = np.array([c[0], c[1], c[2], c[3], 0.0, 5.0])
+    ocfg = _ocfg(N)
+    xo, uo = orc.init_guess(ocfg, xs)
+    st = orc.rti(ocfg, xs, p, xo, uo)
+    assert st.status == 0 and g["status"][0] == 0
+    sc_ = max(1.0, np.abs(xo).max())
+    assert np.abs(g["x"][0] - xo).max() <= 1e-6 * sc_ and np.abs(g["u"][0] - uo).max() <= 1e-6 * sc_
+    a = ws[0, 2] - rot
+    wx = xo[:, 0] * math.cos(a) - xo[:, 1] * math.sin(a) + ws[0, 0]
+    wy = xo[:, 0] * math.sin(a) + xo[:, 1] * math.cos(a) + ws[0, 1]
+    assert np.abs(xy[0, :, 0] - wx).max() <= 1e-6 * sc_ and np.abs(xy[0, :, 1] - wy).max() <= 1e-6 * sc_
+    s.close()
+
+
+def _oracle_closed_loop(t, ws, pv, N, steps, dtp, W=None):
+    """Python restatement of the loop of src/main.cpp:17-26 + src/RosMpc.cpp:55-95 around the oracle."""
+    B = ws.shape[0]
+    ws = ws.copy()
+    xs_prev = [None] * B
+    trace = np.zeros((steps, B, 6))
+    pcfg = orc.default_config(N, dtp)
+    for i in range(B):
+        cfg = _ocfg(N)
+        if W is not None:
+            for m in range(7):
+                cfg.W[m] = W[i, m]
+        xt = ut = None
+        for s in range(steps):
+            rot, c = orc.calc_coeffs(t, ws[i])
+            xs = np.array([0.0, 0.0, rot, ws[i, 3], ws[i, 4], ws[i, 5]])
+            p = np.array([c[0], c[1], c[2], c[3], pv[i, 0], pv[i, 1]])
+            if xt is None:
+                xt, ut = orc.init_guess(cfg, xs)
+            st = orc.rti(cfg, xs, p, xt, ut)
+            dcmd, tcmd = xt[1, 4], xt[1, 5]
+            if st.status != 0:
+                xt = None                                   # reInit on failure (AcadosSolver.cpp:56-59)
+            x = ws[i].copy(); x[4] = dcmd; x[5] = tcmd
+            phi, _, _ = orc.rk4_sens(pcfg, x, np.zeros(2), np.array([0, 0, 0, 0, pv[i, 0], 0.0]))
+            ws[i, :4] = phi[:4]; ws[i, 4] = dcmd; ws[i, 5] = tcmd
+            trace[s, i] = ws[i]
+    return ws, trace
+
+
+def test_closed_loop_matches_oracle_for_a_few_ticks():
+    """Config-5 style: per-instance weights and reference speeds, warm start without shift.  An
+    unconverged RTI sequence amplifies round-off from tick to tick, so the comparison is over a
+    short run; the long run below checks tracking behaviour instead."""
+    N, B, steps, dtp = 40, 24, 6, 1.0 / 30.0
+    t, ws, pv = world_states(B, seed=5)
+    rng = np.random.default_rng(9)
+    W = np.array(capi.default_config(N, 0.35).W[:])[None, :] * rng.uniform(0.5, 2.0, size=(B, 7))
+    s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
+    s.set_track(t)
+    s.set_weights(W)
+    wend, trace, nfail = s.closed_loop(ws, pv, steps, dt_plant=dtp, trace=True, count_failures=True)
+    wo, to = _oracle_closed_loop(t, ws, pv, N, steps, dtp, W)
+    assert nfail == 0
+    err = np.abs(trace - to).reshape(steps, B, 6).max(axis=2)          # [steps, B]
+    assert err[0].max() <= 1e-9 * 100                                   # first tick: one solve apart
+    assert np.median(err[-1]) <= 1e-8 and (err[-1] <= 1e-5).mean() >= 0.9
+    assert np.array_equal(wend, trace[-1])
+    s.close()
+
+
+def test_closed_loop_200_ticks_tracks_the_path():
+    """BASELINE config 5 at reduced batch: 200 ticks of 1/30 s; cars stay on the track."""
+    N, B, steps = 40, 2048, 200
+    t, ws, pv = world_states(B, seed=21)
+    s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
+    s.set_track(t)
+    wend, _, nfail = s.closed_loop(ws, pv, steps, count_failures=True)
+    assert np.isfinite(wend).all()
+    d = np.sqrt(((wend[:, None, 0:2] - t[None, :, :]) ** 2).sum(-1)).min(axis=1)   # distance to the track
+    d0 = np.sqrt(((ws[:, None, 0:2] - t[None, :, :]) ** 2).sum(-1)).min(axis=1)
+    moved = np.sqrt(((wend[:, 0:2] - ws[:, 0:2]) ** 2).sum(-1))
+    assert nfail <= 0.01 * B * steps
+    assert np.median(d) < 0.5 and np.median(d) <= np.median(d0) + 0.05
+    assert np.median(moved) > 5.0                       # 6.7 s at a few m/s
+    assert (np.abs(wend[:, 4]) <= 0.57 + 1e-9).all() and (np.abs(wend[:, 5]) <= 1.0 + 1e-9).all()
+    s.close()

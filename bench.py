@@ -100,6 +100,58 @@ def cpu_baseline(N, seconds_target=12.0):
                       f"one instance per thread; CPU restatement (oracle/), not acados/HPIPM"}
 
 
+def extras(capi, sc, hip, N):
+    """Secondary measurements on one GPU (never `value`): the other BASELINE configs in short form."""
+    ex = {}
+    # config 3, one GPU's share: 131,072 instances in one launch (no tail effect of a small batch)
+    Bl = 131072
+    s = capi.BatchSolver(N=N, dt=0.35, capacity=Bl)
+    x0, p = sc.config2(Bl)
+    s.set_x0(x0); s.set_params(p)
+    s.solve(Bl); s.sync()
+    ms = []
+    for _ in range(3):
+        s.reset(None, Bl)
+        e0, e1 = hip.event(), hip.event()
+        hip.record(e0, s.stream()); s.solve(Bl); hip.record(e1, s.stream())
+        ms.append(hip.elapsed_ms(e0, e1))
+    ex["large_batch"] = {"instances": Bl, "kernel_ms": float(np.median(ms)), "solves_per_s": Bl / (np.median(ms) * 1e-3),
+                         "note": "cold SQP-RTI, config-2 distribution, per-GPU share of config 3"}
+    s.close()
+    # config 4: full SQP (<= 20 iterations, step tolerance 1e-6), N = 100, bounds active
+    B4 = 4096
+    s = capi.BatchSolver(N=100, dt=0.35, capacity=B4)
+    x0, p = sc.config4(B4)
+    s.set_x0(x0); s.set_params(p)
+    e0, e1 = hip.event(), hip.event()
+    hip.record(e0, s.stream()); s.solve(B4, mode=capi.MODE_SQP, max_iter=20, tol=1e-6); hip.record(e1, s.stream())
+    t4 = hip.elapsed_ms(e0, e1)
+    g = s.get(B4)
+    hist = np.bincount(g["sqp_iters"], minlength=21)[:21].tolist()
+    ex["config4_sqp_N100"] = {"instances": B4, "kernel_ms": t4, "converged_frac": float((g["status"] == 0).mean()),
+                              "sqp_iters_hist": hist, "mean_ipm_iters": float(g["ipm_iters"].mean()),
+                              "qp_solves_per_s": float(g["sqp_iters"].sum() / (t4 * 1e-3))}
+    s.close()
+    # config 5 (short form): closed loop, 65,536 vehicles x 20 ticks, per-instance weights / v_ref
+    B5, ticks = 65536, 20
+    track = sc.test_track()
+    ws, pv = sc.cars_on_track(B5, track)
+    rng = np.random.default_rng(5)
+    s = capi.BatchSolver(N=N, dt=0.35, capacity=B5)
+    s.set_track(track)
+    s.set_weights(np.array(s.cfg.W[:])[None, :] * rng.uniform(0.5, 2.0, size=(B5, 7)))
+    s.closed_loop(ws, pv, 2)
+    t = time.perf_counter()
+    s.closed_loop(ws, pv, ticks)
+    dt5 = time.perf_counter() - t
+    ex["config5_closed_loop"] = {"vehicles": B5, "ticks": ticks, "wall_s": dt5,
+                                 "vehicle_ticks_per_s": B5 * ticks / dt5,
+                                 "note": "front-end + SQP-RTI + plant per tick on the device, host transfers of the "
+                                         "states at both ends included"}
+    s.close()
+    return ex
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +160,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
     args = ap.parse_args()
 
     import torch
@@ -220,6 +273,8 @@ def main():
                    "kernel_ms": kernel_ms_warm, "mean_ipm_iters": n_ipm_warm}
     if dt_nogather:
         out["multi_gpu"] = {"with_gather": value, "without_gather": total_solves / dt_nogather}
+    if rank == 0 and world == 1 and not args.no_extras:
+        out["extras"] = extras(capi, sc, hip, N)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N)
     if rank == 0:

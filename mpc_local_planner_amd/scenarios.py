@@ -91,3 +91,31 @@ def config4(B, start=0, seed=SEED, vref=5.0):
     kappa = uniform(seed, i, 9, -0.05, 0.05)
     c3 = uniform(seed, i, 10, -0.002, 0.002)
     return _pack(psi0, v, delta, thr, pitch, epsi0, cte0, kappa, c3, vref)
+
+
+def test_track():
+    """The reference's demo track (util::getTestTrack, src/utilities.cpp:59-72) as input data:
+    theta accumulates 2*pi/400 in fp64 until it reaches 2*pi, which yields 401 points, the last a
+    near-duplicate of the first."""
+    import math
+    pts = []
+    theta, step = 0.0, 2 * math.pi / 400.0
+    while theta < 2 * math.pi:
+        pts.append((2 * 20 * math.cos(theta), 20 * math.sin(1 * theta) + 20 / 1.2 * math.sin(3 * theta)))
+        theta += step
+    return np.array(pts)
+
+
+def cars_on_track(B, track, seed=5, lateral=0.3, heading=0.1, v=(2.0, 6.0), vref=(3.0, 7.0)):
+    """World-frame states near `track` heading along it (config 5), clear of the seam where the
+    last track point duplicates the first, and (pitch, v_ref) per vehicle."""
+    rng = np.random.default_rng(seed)
+    idx = rng.integers(8, track.shape[0] - 13, size=B)
+    d = track[idx + 1] - track[idx]
+    hd = np.arctan2(d[:, 1], d[:, 0])
+    ws = np.zeros((B, 6))
+    ws[:, 0:2] = track[idx] + rng.normal(0, lateral, size=(B, 2))
+    ws[:, 2] = hd + rng.normal(0, heading, size=B)
+    ws[:, 3] = rng.uniform(v[0], v[1], size=B)
+    pv = np.stack([np.zeros(B), rng.uniform(vref[0], vref[1], size=B)], axis=1)
+    return ws, pv

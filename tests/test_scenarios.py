@@ -21,3 +21,9 @@ def test_distributions_follow_survey_8d():
     assert abs(p[:, 0].std() - 0.5) < 0.05
     x4, p4 = sc.config4(1024)
     assert (np.abs(x4[:, 4]) >= 0.45).all() and (x4[:, 5] >= 0.8).all() and (np.abs(p4[:, 0]) >= 2.0).all()
+
+
+def test_test_track_matches_the_oracle_restatement():
+    from oracle import oracle as orc
+    a, b = sc.test_track(), orc.test_track()
+    assert a.shape == (401, 2) and np.abs(a - b).max() < 1e-12

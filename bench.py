@@ -24,8 +24,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP64_VECTOR_PEAK_TFLOPS = 78.6   # = 1/2 of the 157.3 TF fp32 vector spec (MI355X_MICROARCH.md)
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # = 1/2 of the 157.3 TF fp32 vector spec (MI355X_MICROARCH.md); also the fp64 MFMA peak
 HBM_PEAK_GBPS = 8000.0
+# HBM bytes per 4096-instance launch from the PMC passes committed under profiles/r1c/ (rocprofv3
+# cannot be read from inside this process): 2 x FETCH_SIZE (gfx950 tallies 128-B requests as 64 B;
+# the factor is calibrated for wide streaming reads only, so this is an upper bound) + WRITE_SIZE.
+PMC_TRAFFIC_BYTES_PER_LAUNCH_B4096_N40 = int((2 * 23968.8 + 86094.4) * 1024)
 
 
 def flops_per_solve(N, n_ipm):
@@ -263,7 +267,10 @@ def main():
         tf = fl / (kernel_ms * 1e-3) / 1e12
         out["roofline"] = {
             "bound": "fp64_valu", "kernel": "nmpc_solve_kernel", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+            "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
+            "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH_B4096_N40 if (B == 4096 and N == 40) else None,
+            "note": "fp64 vector FMA rate (no MFMA-shaped work; the fp64 MFMA peak is the same 78.6 TF); measured "
+                    "binding resources are the LDS pipe and serial-recursion latency, see DESIGN.md section 5",
             "kernel_ms": kernel_ms, "flops_per_solve": flops_per_solve(N, n_ipm_cold),
             "hbm": {"bound": "hbm", "achieved": by / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": by / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,

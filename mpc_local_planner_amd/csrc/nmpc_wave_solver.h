@@ -1,5 +1,5 @@
-// nmpc_wave_solver.h -- one SQP-RTI solve of the path-tracking OCP by ONE 64-lane
-// wavefront (gfx950).  This is the body of the HIP kernel in nmpc_hip.hip; it is
+// nmpc_wave_solver.h -- one SQP-RTI solve of the path-tracking OCP by ONE workgroup of one
+// 64-lane wavefront (N <= 63) or two (N <= 127) on gfx950.  This is the body of the HIP kernel in nmpc_hip.hip; it is
 // written against a small "wave policy" W (lane id, LDS pointer, wave sync,
 // cross-lane reads and reductions) so that tests can also run the very same
 // source on a CPU lane emulator (tests/emu/) -- the product only ever
@@ -25,7 +25,9 @@
 //     Every lane addresses LDS through pointers set up once per sweep (stride 0 for constant
 //     columns), so the loop body has no branches and no index arithmetic.
 //   * vector sweeps (corrector backward, both forward passes): lane c = lane & 7 owns one row /
-//     column, the recursion vector is replicated and re-gathered through LDS once per stage.
+//     column, the 6-vector of the recursion is wave-uniform and re-gathered with v_readlane, so
+//     the serial path has no LDS round trip.
+//   The sweeps run on the first wave only; a second wave (N > 63) takes part in the stage layout.
 //   Rows v,delta,thr of [B A] are constants of this model (a33, a35, b31, h) and columns X,Y are
 //   unit vectors: they live in a small constant table, not per stage.
 #pragma once

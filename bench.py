@@ -212,8 +212,9 @@ def main():
             if events is not None:
                 hip.record(events[2 * s + 1], stream)
             if gather and world > 1:
-                solver.sync()
+                solver.sync()                       # records complete before RCCL reads them
                 sharding.gather_controls(ctrl_local, total=world * B)
+                torch.cuda.synchronize()            # ... and gathered before the next solve overwrites them
 
     def timed(steps, cold, gather, with_events=False):
         events = [hip.event() for _ in range(2 * steps)] if with_events else None

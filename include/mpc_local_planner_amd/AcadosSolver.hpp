@@ -17,6 +17,7 @@
 #include <iostream>
 #include <sstream>
 #include <stdexcept>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -147,7 +148,16 @@ class PathTracking : public Solver {
         init();
         setInitGuess(state);
     }
+    // From a ROS parameter file shaped like config/mpc_params.yaml (what the reference reads at code
+    // generation, acados/mpcPathTracking.py:83-92); throws std::runtime_error naming the bad key.
+    PathTracking(const State &state, const std::string &paramsFile, int capacity = 1, int device = 0)
+        : capacity_{capacity}, device_{device} {
+        check(nmpc_config_from_file(paramsFile.c_str(), &cfg_, &run_), "nmpc_config_from_file");
+        init();
+        setInitGuess(state);
+    }
     ~PathTracking() override { freeAllocated(); }
+    const nmpc_run_params &runParams() const { return run_; }    // defaults unless built from a file
 
     void setParams(const Params &params) override {              // AcadosPathTracking.cpp:17-24
         const auto p = params.toVec();
@@ -221,6 +231,7 @@ class PathTracking : public Solver {
     }
 
     nmpc_config cfg_{};
+    nmpc_run_params run_{NMPC_MODE_RTI, 30.0, 5.0, 1.0};
     int capacity_ = 1;
     int device_ = 0;
 };

@@ -53,6 +53,22 @@ typedef struct nmpc_handle nmpc_handle;
 /* Reference defaults for everything but N and dt. */
 int nmpc_default_config(nmpc_config *cfg, int N, double dt);
 
+/* Run-time parameters of the same file that are not part of the OCP. */
+typedef struct nmpc_run_params {
+    int mode;                  /* nlp_solver_type (config/mpc_params.yaml:38): NMPC_MODE_RTI or NMPC_MODE_SQP */
+    double loop_hz;            /* loop_Hz (:9; src/main.cpp:14), default 30 */
+    double path_tracking_vel;  /* (:44; src/RosMpc.cpp:20), default 5.0 */
+    double steering_ratio;     /* (:62; src/RosMpc.cpp:34), default 1.0 */
+} nmpc_run_params;
+
+/* Replaces the code-generation-time read of the ROS parameter file (acados/mpcPathTracking.py:83-92,
+ * 105-108,126; CMakeLists.txt:29-40) and the run-time reads of src/RosMpc.cpp:20,34: fills cfg (and run,
+ * if not NULL) from a file shaped like config/mpc_params.yaml.  Keys the reference's code generation
+ * indexes (mpc_N, mpc_dt, wheelbase, the four *_range lists, nlp_solver_type) are required, as there;
+ * W and the interior-point options keep the values of nmpc_default_config.  Host only, needs no GPU.
+ * NMPC_EINVAL with the reason in nmpc_last_error() for unreadable files, missing or malformed keys. */
+int nmpc_config_from_file(const char *path, nmpc_config *cfg, nmpc_run_params *run);
+
 /* Replaces path_tracking_acados_create_capsule + _create_with_discretization
  * (src/AcadosPathTracking.cpp:28-49) for `capacity` instances on HIP device `device`.
  * All device memory, the stream and the iterate buffers are owned by the handle.

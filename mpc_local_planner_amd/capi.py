@@ -27,8 +27,13 @@ class Config(C.Structure):
     ]
 
 
+class RunParams(C.Structure):
+    _fields_ = [("mode", C.c_int), ("loop_hz", C.c_double), ("path_tracking_vel", C.c_double),
+                ("steering_ratio", C.c_double)]
+
+
 EXPORTS = [
-    "nmpc_default_config", "nmpc_create", "nmpc_destroy", "nmpc_set_x0", "nmpc_set_params",
+    "nmpc_default_config", "nmpc_config_from_file", "nmpc_create", "nmpc_destroy", "nmpc_set_x0", "nmpc_set_params",
     "nmpc_set_inputs_device", "nmpc_set_weights", "nmpc_set_bounds", "nmpc_reset", "nmpc_set_iterate",
     "nmpc_solve",
     "nmpc_sync", "nmpc_get", "nmpc_get_controls", "nmpc_device_ptr", "nmpc_stream",
@@ -55,6 +60,7 @@ def lib():
     l = C.CDLL(LIB_PATH)
     dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
     l.nmpc_default_config.argtypes = [C.POINTER(Config), C.c_int, C.c_double]
+    l.nmpc_config_from_file.argtypes = [C.c_char_p, C.POINTER(Config), C.POINTER(RunParams)]
     l.nmpc_create.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.POINTER(vp)]
     l.nmpc_destroy.argtypes = [vp]
     l.nmpc_set_x0.argtypes = [vp, dp, C.c_int]
@@ -100,6 +106,13 @@ def default_config(N=40, dt=0.35, **over):
         else:
             setattr(cfg, k, v)
     return cfg
+
+
+def config_from_file(path):
+    """(Config, RunParams) from a ROS parameter file shaped like the reference's config/mpc_params.yaml."""
+    cfg, run = Config(), RunParams()
+    check(lib().nmpc_config_from_file(os.fsencode(path), C.byref(cfg), C.byref(run)), "nmpc_config_from_file")
+    return cfg, run
 
 
 def _dp(a):

@@ -10,6 +10,7 @@
 
 #define NMPC_DEV __device__ __forceinline__
 #include "nmpc_wave_solver.h"
+#include "nmpc_params_file.h"
 #include "nmpc_frontend.h"
 
 #include "../../include/nmpc.h"
@@ -299,6 +300,98 @@ int nmpc_default_config(nmpc_config *c, int N, double dt)
     c->ipm_tol_mu = 1e-10;
     c->ipm_tol_lin = 1e-10;
     c->ipm_tol_comp = 1e-11;
+    return NMPC_OK;
+}
+
+int nmpc_config_from_file(const char *path, nmpc_config *cfg, nmpc_run_params *run)
+{
+    if (!path || !cfg) return NMPC_EINVAL;
+    FILE *f = fopen(path, "r");
+    if (!f) {
+        snprintf(g_err, sizeof(g_err), "nmpc_config_from_file: cannot open %s", path);
+        return NMPC_EINVAL;
+    }
+    nmpcy::Table t;
+    std::string err;
+    const bool parsed = nmpcy::parse(f, t, err);
+    fclose(f);
+    if (!parsed) {
+        snprintf(g_err, sizeof(g_err), "nmpc_config_from_file: %s: %s", path, err.c_str());
+        return NMPC_EINVAL;
+    }
+    std::string pre;
+    if (!nmpcy::find_prefix(t, "mpc_N", &pre)) {
+        snprintf(g_err, sizeof(g_err), "nmpc_config_from_file: %s: missing key mpc_N", path);
+        return NMPC_EINVAL;
+    }
+    // required keys: the ones the reference's code generation indexes (mpcPathTracking.py:9,91-92,105-108,126)
+    auto numbers = [&](const char *key, int n, double *out, bool required) -> int {
+        nmpcy::Table::const_iterator it = t.find(pre + key);
+        if (it == t.end()) {
+            if (!required) return 1;
+            snprintf(g_err, sizeof(g_err), "nmpc_config_from_file: %s: missing key %s", path, key);
+            return -1;
+        }
+        if ((int)it->second.size() != n) {
+            snprintf(g_err, sizeof(g_err), "nmpc_config_from_file: %s: %s needs %d value(s)", path, key, n);
+            return -1;
+        }
+        for (int i = 0; i < n; ++i)
+            if (!nmpcy::to_double(it->second[i], &out[i])) {
+                snprintf(g_err, sizeof(g_err), "nmpc_config_from_file: %s: %s: '%s' is not a number", path, key,
+                         it->second[i].c_str());
+                return -1;
+            }
+        return 0;
+    };
+    double nn = 0.0, dt = 0.0, wb = 0.0, r[4][2];
+    if (numbers("mpc_N", 1, &nn, true) < 0 || numbers("mpc_dt", 1, &dt, true) < 0 ||
+        numbers("wheelbase", 1, &wb, true) < 0 || numbers("steering_angle_dot_range", 2, r[0], true) < 0 ||
+        numbers("throttle_dot_range", 2, r[1], true) < 0 || numbers("steering_angle_range", 2, r[2], true) < 0 ||
+        numbers("throttle_range", 2, r[3], true) < 0)
+        return NMPC_EINVAL;
+    if (nn != (double)(int)nn || nn < 1 || nn > 127 || !(dt > 0.0) || !(wb > 0.0)) {
+        snprintf(g_err, sizeof(g_err), "nmpc_config_from_file: %s: mpc_N in 1..127, mpc_dt > 0, wheelbase > 0", path);
+        return NMPC_EINVAL;
+    }
+    for (int i = 0; i < 4; ++i)
+        if (!(r[i][0] < r[i][1])) {
+            snprintf(g_err, sizeof(g_err), "nmpc_config_from_file: %s: a range needs lower < upper", path);
+            return NMPC_EINVAL;
+        }
+    nmpcy::Table::const_iterator st = t.find(pre + "nlp_solver_type");
+    int mode;
+    if (st == t.end() || st->second.size() != 1) {
+        snprintf(g_err, sizeof(g_err), "nmpc_config_from_file: %s: missing key nlp_solver_type", path);
+        return NMPC_EINVAL;
+    } else if (st->second[0] == "SQP_RTI") {
+        mode = NMPC_MODE_RTI;
+    } else if (st->second[0] == "SQP") {
+        mode = NMPC_MODE_SQP;
+    } else {
+        snprintf(g_err, sizeof(g_err), "nmpc_config_from_file: %s: nlp_solver_type '%s' (SQP or SQP_RTI)", path,
+                 st->second[0].c_str());
+        return NMPC_EINVAL;
+    }
+    nmpc_run_params rp;
+    rp.mode = mode;
+    rp.loop_hz = 30.0;              // config/mpc_params.yaml:9, src/main.cpp:14
+    rp.path_tracking_vel = 5.0;     // config/mpc_params.yaml:44
+    rp.steering_ratio = 1.0;        // default of src/RosMpc.cpp:34
+    if (numbers("loop_Hz", 1, &rp.loop_hz, false) < 0 || numbers("path_tracking_vel", 1, &rp.path_tracking_vel, false) < 0 ||
+        numbers("steering_ratio", 1, &rp.steering_ratio, false) < 0)
+        return NMPC_EINVAL;
+    if (!(rp.loop_hz > 0.0) || rp.steering_ratio == 0.0) {
+        snprintf(g_err, sizeof(g_err), "nmpc_config_from_file: %s: loop_Hz > 0 and steering_ratio != 0", path);
+        return NMPC_EINVAL;
+    }
+    nmpc_default_config(cfg, (int)nn, dt);
+    cfg->wheelbase = wb;
+    cfg->lbu[0] = r[0][0]; cfg->ubu[0] = r[0][1];
+    cfg->lbu[1] = r[1][0]; cfg->ubu[1] = r[1][1];
+    cfg->lbx[0] = r[2][0]; cfg->ubx[0] = r[2][1];
+    cfg->lbx[1] = r[3][0]; cfg->ubx[1] = r[3][1];
+    if (run) *run = rp;
     return NMPC_OK;
 }
 

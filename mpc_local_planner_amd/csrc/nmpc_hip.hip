@@ -47,38 +47,131 @@ struct GpuWave {
         if (NW == 1) wsync(); else __syncthreads();
     }
     __device__ __forceinline__ void sync_lockstep() { wsync(); }
-    // forward-sweep stage data: kr[0,2,..,12], rw[0,4,..,20], rbp[0] as 14 x ds_read_b64 and one wait.
-    // Written in asm because the compiler merges such loads into ds_read2_b64 (8 LDS cycles per
-    // pair instead of 2+2) and offers no switch against it.
-    __device__ __forceinline__ void lds_gather_fwd(const double *kr, const double *rw, const double *rbp,
-                                                   double (&kk)[7], double (&rr)[6], double *rbv)
+    // ---- vector sweeps.  A stage is ONE asm statement: the loads of the NEXT stage's data are
+    // issued first, then the multiply-add chain of the current stage runs on registers, then the
+    // result is stored and the loads are waited for.  v_fmac_f64 with a DPP row broadcast
+    // (row_newbcast:C, the only DPP control fp64 has) multiplies by lane C of the caller's 16-lane
+    // row, so the recursion vector never leaves the VALU.  Hand-written because (a) the compiler
+    // merges the strided 8-byte loads into ds_read2_b64 (8 LDS cycles per pair instead of 2+2),
+    // (b) it does not fold a 64-bit DPP move into the multiply-add, (c) a load that is waited for
+    // in a later statement is not something C++ can express.  Every register the chain reads
+    // through DPP is written by an fp64 VALU instruction at least one instruction earlier
+    // (tools/micro/dpp_latency.hip: the dependent issue distance of fp64 covers the DPP wait states).
+    static __device__ __forceinline__ unsigned lds_addr(const double *p)
     {
         typedef __attribute__((address_space(3))) const double lds_cd;
-        const unsigned ak = (unsigned)(unsigned long long)(lds_cd *)kr;
-        const unsigned ar = (unsigned)(unsigned long long)(lds_cd *)rw;
-        const unsigned ab = (unsigned)(unsigned long long)(lds_cd *)rbp;
-        double v;
+        return (unsigned)(unsigned long long)(lds_cd *)p;
+    }
+    // d[0..5] = p1[0,6,..,30], d[6,7] = p3[0,2], d[8] = p2[0]
+    __device__ __forceinline__ void fwd_fetch(const double *p1, const double *p3, const double *p2, double (&d)[9])
+    {
         asm volatile(
-            "ds_read_b64 %0, %14\n\t"
-            "ds_read_b64 %1, %14 offset:16\n\t"
-            "ds_read_b64 %2, %14 offset:32\n\t"
-            "ds_read_b64 %3, %14 offset:48\n\t"
-            "ds_read_b64 %4, %14 offset:64\n\t"
-            "ds_read_b64 %5, %14 offset:80\n\t"
-            "ds_read_b64 %6, %14 offset:96\n\t"
-            "ds_read_b64 %7, %15\n\t"
-            "ds_read_b64 %8, %15 offset:32\n\t"
-            "ds_read_b64 %9, %15 offset:64\n\t"
-            "ds_read_b64 %10, %15 offset:96\n\t"
-            "ds_read_b64 %11, %15 offset:128\n\t"
-            "ds_read_b64 %12, %15 offset:160\n\t"
-            "ds_read_b64 %13, %16\n\t"
+            "ds_read_b64 %8, %11\n\t"
+            "ds_read_b64 %6, %10\n\t"
+            "ds_read_b64 %7, %10 offset:16\n\t"
+            "ds_read_b64 %2, %9 offset:96\n\t"
+            "ds_read_b64 %3, %9 offset:144\n\t"
+            "ds_read_b64 %4, %9 offset:192\n\t"
+            "ds_read_b64 %5, %9 offset:240\n\t"
+            "ds_read_b64 %0, %9\n\t"
+            "ds_read_b64 %1, %9 offset:48\n\t"
             "s_waitcnt lgkmcnt(0)"
-            : "=&v"(kk[0]), "=&v"(kk[1]), "=&v"(kk[2]), "=&v"(kk[3]), "=&v"(kk[4]), "=&v"(kk[5]), "=&v"(kk[6]),
-              "=&v"(rr[0]), "=&v"(rr[1]), "=&v"(rr[2]), "=&v"(rr[3]), "=&v"(rr[4]), "=&v"(rr[5]), "=&v"(v)
-            : "v"(ak), "v"(ar), "v"(ab)
+            : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]),
+              "=&v"(d[7]), "=&v"(d[8])
+            : "v"(lds_addr(p1)), "v"(lds_addr(p3)), "v"(lds_addr(p2))
             : "memory");
-        *rbv = v;
+    }
+    __device__ __forceinline__ void fwd_stage(double (&cur)[9], double (&nxt)[9], const double *p1,
+                                              const double *p3, const double *p2, double *sw, double &val)
+    {
+        double t;
+        asm volatile(
+            "ds_read_b64 %[n8], %[a2]\n\t"
+            "ds_read_b64 %[n6], %[a3]\n\t"
+            "ds_read_b64 %[n7], %[a3] offset:16\n\t"
+            "ds_read_b64 %[n2], %[a1] offset:96\n\t"
+            "ds_read_b64 %[n3], %[a1] offset:144\n\t"
+            "ds_read_b64 %[n4], %[a1] offset:192\n\t"
+            "ds_read_b64 %[n5], %[a1] offset:240\n\t"
+            "ds_read_b64 %[n0], %[a1]\n\t"
+            "ds_read_b64 %[n1], %[a1] offset:48\n\t"
+            "v_fmac_f64_dpp %[iv], %[val], %[e0] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b64 %[t], 0\n\t"
+            "v_fmac_f64_dpp %[t], %[val], %[e1] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[iv], %[val], %[c2] row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[t], %[val], %[c3] row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[iv], %[val], %[c4] row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[t], %[val], %[c5] row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f64 %[val], %[iv], %[t]\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64_dpp %[val], %[val], %[c0] row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64_dpp %[val], %[val], %[c1] row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+            "ds_write_b64 %[sw], %[val]\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : [n0] "=&v"(nxt[0]), [n1] "=&v"(nxt[1]), [n2] "=&v"(nxt[2]), [n3] "=&v"(nxt[3]), [n4] "=&v"(nxt[4]),
+              [n5] "=&v"(nxt[5]), [n6] "=&v"(nxt[6]), [n7] "=&v"(nxt[7]), [n8] "=&v"(nxt[8]), [t] "=&v"(t),
+              [val] "+v"(val), [iv] "+v"(cur[8])
+            : [c0] "v"(cur[0]), [c1] "v"(cur[1]), [c2] "v"(cur[2]), [c3] "v"(cur[3]), [c4] "v"(cur[4]),
+              [c5] "v"(cur[5]), [e0] "v"(cur[6]), [e1] "v"(cur[7]), [a1] "v"(lds_addr(p1)), [a3] "v"(lds_addr(p3)),
+              [a2] "v"(lds_addr(p2)), [sw] "v"(lds_addr(sw))
+            : "memory");
+    }
+    // d[0..2] = tv[0..2], d[3] = dg[0], d[4,5] = ab[0,1]
+    __device__ __forceinline__ void bwd_fetch(const double *tv, const double *dg, const double *ab, double (&d)[6])
+    {
+        asm volatile(
+            "ds_read_b64 %0, %6\n\t"
+            "ds_read_b64 %1, %6 offset:8\n\t"
+            "ds_read_b64 %2, %6 offset:16\n\t"
+            "ds_read_b64 %3, %7\n\t"
+            "ds_read_b64 %4, %8\n\t"
+            "ds_read_b64 %5, %8 offset:8\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5])
+            : "v"(lds_addr(tv)), "v"(lds_addr(dg)), "v"(lds_addr(ab))
+            : "memory");
+    }
+    __device__ __forceinline__ void bwd_stage(double (&cur)[6], double (&nxt)[6], const double *tv, const double *dg,
+                                              const double *ab, double *kfw, double cb0, double cb1, double cb2,
+                                              double keep, double &res)
+    {
+        double t;
+        asm volatile(
+            "ds_read_b64 %[n0], %[atv]\n\t"
+            "ds_read_b64 %[n1], %[atv] offset:8\n\t"
+            "ds_read_b64 %[n2], %[atv] offset:16\n\t"
+            "ds_read_b64 %[n3], %[adg]\n\t"
+            "ds_read_b64 %[n4], %[aab]\n\t"
+            "ds_read_b64 %[n5], %[aab] offset:8\n\t"
+            "v_fmac_f64_dpp %[g], %[res], %[t0] row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b64 %[t], 0\n\t"
+            "v_fmac_f64_dpp %[t], %[res], %[t1] row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[g], %[res], %[t2] row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[t], %[res], %[cb0] row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[g], %[res], %[cb1] row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[t], %[res], %[cb2] row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f64 %[g], %[g], %[t]\n\t"
+            "v_mul_f64 %[res], %[keep], %[g]\n\t"
+            "v_fmac_f64_dpp %[res], %[g], %[ka] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[res], %[g], %[kb] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+            "ds_write_b64 %[kfw], %[res]\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : [n0] "=&v"(nxt[0]), [n1] "=&v"(nxt[1]), [n2] "=&v"(nxt[2]), [n3] "=&v"(nxt[3]), [n4] "=&v"(nxt[4]),
+              [n5] "=&v"(nxt[5]), [t] "=&v"(t), [res] "+v"(res), [g] "+v"(cur[3])
+            : [t0] "v"(cur[0]), [t1] "v"(cur[1]), [t2] "v"(cur[2]), [ka] "v"(cur[4]), [kb] "v"(cur[5]),
+              [cb0] "v"(cb0), [cb1] "v"(cb1), [cb2] "v"(cb2), [keep] "v"(keep), [atv] "v"(lds_addr(tv)),
+              [adg] "v"(lds_addr(dg)), [aab] "v"(lds_addr(ab)), [kfw] "v"(lds_addr(kfw))
+            : "memory");
+    }
+    // acc + (src of lane C of the caller's 16-lane row) * coef, fused (single use outside the sweeps' asm)
+    template <int C>
+    __device__ __forceinline__ double fmac_row(double acc, double src, double coef)
+    {
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc)
+                     : "v"(src), "v"(coef), "n"(C));
+        return acc;
     }
     // keep the loads issued above this point together (one wait instead of one per load)
     __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }

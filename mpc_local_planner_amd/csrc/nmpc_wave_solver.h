@@ -25,8 +25,9 @@
 //     Every lane addresses LDS through pointers set up once per sweep (stride 0 for constant
 //     columns), so the loop body has no branches and no index arithmetic.
 //   * vector sweeps (corrector backward, both forward passes): lane c = lane & 7 owns one row /
-//     column, the 6-vector of the recursion is wave-uniform and re-gathered with v_readlane, so
-//     the serial path has no LDS round trip.
+//     column; the 6-vector of the recursion stays in lanes of the wave and is consumed through
+//     v_fmac_f64 with a DPP row broadcast (W::fmac_row), so the serial path has no LDS round
+//     trip and no v_readlane.
 //   The sweeps run on the first wave only; a second wave (N > 63) takes part in the stage layout.
 //   Rows v,delta,thr of [B A] are constants of this model (a33, a35, b31, h) and columns X,Y are
 //   unit vectors: they live in a small constant table, not per stage.
@@ -76,23 +77,32 @@ struct InstanceIO {
 // Everything read as a pair sits on a 16-byte boundary (ds_read_b128); the remaining reads are
 // single ds_read_b64 -- the ds_read2_b64 form the compiler would otherwise merge them into costs
 // 4x the LDS cycles of either (MI355X_MICROARCH.md, LDS table), and this kernel is LDS-bound.
-constexpr int ST = 50;          // per stage
-constexpr int O_BA = 0;         // [c][4]: columns u0,u1,psi,v,delta,thr x rows X,Y,psi,(pad) of [B A]
-constexpr int O_KP = 24;        // (K0[c],K1[c]) c = X..thr, then (kff0,kff1)
-constexpr int O_INV = 38;       // rows of -inv(Huu): (-i00,-i01), (-i01,-i11)
-constexpr int O_D = 42;         // slot k: rb_k as [0,1,2,-,3,4,5,-] -> z_{k+1}[8] = du,dx -> dG_k[4]
-constexpr int O_TAB = 24;       // input view of the factor sweep: gam[4],Q00,Q01,Q02,(unused)
-constexpr int O_G = 32;         //   G[8]
-// pseudo-stage -1 holds the constant tables in [0,42) and z_0 in its O_D
-constexpr int C_BOT = 0;        // [c][4]: rows v,delta,thr,(pad) of the six variable columns
-constexpr int C_UNIT = 24;      // (1,0,0,-),(0,1,0,-): rows X,Y,psi of columns X,Y
-constexpr int C_ZERO = 32;      // 0,0,0,0
+// A stage holds six column groups of six doubles, one per variable column g = u0,u1,psi,v,delta,thr
+// of [B A]:  (K0[g],K1[g]) | (BA[X][g],BA[Y][g]) | BA[psi][g] | unused.   The gain slots of the
+// groups u0,u1 stay zero.  With this spacing a ROW of [B A] (offset G_XY + r) and a row of K
+// (offset a) are both six loads at 6-double intervals from one base: the forward sweep fetches
+// the coefficients of its row, whatever its role, with one address register.
+constexpr int ST = 54;          // per stage
+constexpr int GS = 6;           // group stride
+constexpr int G_K = 0;          //   gain pair of the column (psi..thr); zero in the groups u0,u1
+constexpr int G_XY = 2;         //   rows X,Y (pair), row psi at +2
+constexpr int O_E = 36;         // (K0[X],K1[X]), (K0[Y],K1[Y]), (kff0,kff1)
+constexpr int O_INV = 42;       // rows of -inv(Huu): (-i00,-i01), (-i01,-i11)
+constexpr int O_D = 46;         // slot k: rb_k as [0,1,2,-,3,4,5,-] -> z_{k+1}[8] = du,dx -> dG_k[4]
+// input view of the factor sweep, overlaying the gain/inverse slots it writes afterwards
+constexpr int I_GAM01 = 12, I_GAM23 = 18, I_Q0 = 24, I_Q2 = 30;   // (gam0,gam1) (gam2,gam3) (Q00,Q01) (Q02,-)
+constexpr int I_G = 36;         // G[8]
+// pseudo-stage -1: its groups hold rows v,delta,thr of the six variable columns (constants) in
+// the (X,Y,psi) positions; its O_D holds z_0
 // exchange area after the stages
 constexpr int X_P = 0;          // Pt rows [6][8]: P[m][0..5], p[m], pad
 constexpr int X_M = 48;         // Mt col-major [9][6] (+ slack read by the idle lanes)
 constexpr int X_HU = 116;       // (Ht[0][j], Ht[1][j]) j = 0..8, then the unit columns (1,0),(0,1)
 constexpr int X_DUM = 138;      // dummy target for lanes with nothing to store
-constexpr int X_SIZE = 142;
+constexpr int X_UNIT = 142;     // (1,0,0,-),(0,1,0,-): rows X,Y,psi of columns X,Y
+constexpr int X_ZERO = 150;     // 0,0,0,0
+constexpr int X_FT = 154;       // 1,0,0,0,1,0: forward-sweep coefficients of dx_X, dx_Y for the state rows
+constexpr int X_SIZE = 160;
 // horizons beyond 63 use two waves per instance (lane = node needs 128 threads); their cross-wave
 // reductions and the x_{k+1} hand-over go through a small extra area owned by the wave policy
 constexpr int X_POLICY = 8 + 128;
@@ -195,6 +205,8 @@ NMPC_DEV void rk4_sens(const Problem &pb, const double *x, const double *u, doub
 #define NMPC_ZQ(a, q) ((q) == 0 ? (a)[0] : (q) == 1 ? (a)[1] : (q) == 2 ? (a)[6] : (a)[7])
 // variable-column index of z index j (u0,u1,-,-,psi,v,delta,thr) -> 0,1,-,-,2,3,4,5
 #define NMPC_VCOL(j) ((j) < 2 ? (j) : (j) - 2)
+// stage offset of the gain pair (K0[c],K1[c]), c = X,Y,psi,v,delta,thr; c = 6: (kff0,kff1)
+#define NMPC_KOFF(c) ((c) < 2 ? O_E + 2 * (c) : (c) < 6 ? GS * (c) + G_K : O_E + 4)
 
 template <class W>
 NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
@@ -259,29 +271,35 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 rb[4] += d[4];
                 rb[5] += d[5];
             }
-            if (act) {   // variable rows X,Y,psi of [B A], column-major, columns u0,u1,psi,v,delta,thr
-                double *c = stg + tid * ST + O_BA;
-                st2(c + 0, aX[4], aY[4]);  st2(c + 2, aP[4], 0.0);
-                st2(c + 4, aX[5], aY[5]);  st2(c + 6, aP[5], 0.0);
-                st2(c + 8, aX[0], aY[0]);  st2(c + 10, aP[0], 0.0);
-                st2(c + 12, aX[1], aY[1]); st2(c + 14, aP[1], 0.0);
-                st2(c + 16, aX[2], aY[2]); st2(c + 18, aP[2], 0.0);
-                st2(c + 20, aX[3], aY[3]); st2(c + 22, aP[3], 0.0);
+            if (act) {   // variable rows X,Y,psi of [B A] into the column groups u0,u1,psi,v,delta,thr
+                double *c = stg + tid * ST + G_XY;
+                st2(c + 0 * GS, aX[4], aY[4]); st2(c + 0 * GS + 2, aP[4], 0.0);
+                st2(c + 1 * GS, aX[5], aY[5]); st2(c + 1 * GS + 2, aP[5], 0.0);
+                st2(c + 2 * GS, aX[0], aY[0]); st2(c + 2 * GS + 2, aP[0], 0.0);
+                st2(c + 3 * GS, aX[1], aY[1]); st2(c + 3 * GS + 2, aP[1], 0.0);
+                st2(c + 4 * GS, aX[2], aY[2]); st2(c + 4 * GS + 2, aP[2], 0.0);
+                st2(c + 5 * GS, aX[3], aY[3]); st2(c + 5 * GS + 2, aP[3], 0.0);
+                // gain slots of the input columns: the forward sweep's input lanes read them as
+                // their (zero) coefficients of du
+                st2(c - G_XY + 0 * GS + G_K, 0.0, 0.0);
+                st2(c - G_XY + 1 * GS + G_K, 0.0, 0.0);
             }
             if (!tables_ready) {   // constant rows (v,delta,thr) of [B A]: identical on every lane
                 a33 = aV[1]; a35 = aV[3]; b31 = aV[5];   // functions of dt only
                 if (tid == 0) {
-                    double *c = ct + C_BOT;
-                    c[0] = 0.0;  c[1] = h;    c[2] = 0.0;  c[3] = 0.0;     // u0
-                    c[4] = b31;  c[5] = 0.0;  c[6] = h;    c[7] = 0.0;     // u1
-                    c[8] = 0.0;  c[9] = 0.0;  c[10] = 0.0; c[11] = 0.0;    // psi
-                    c[12] = a33; c[13] = 0.0; c[14] = 0.0; c[15] = 0.0;    // v
-                    c[16] = 0.0; c[17] = 1.0; c[18] = 0.0; c[19] = 0.0;    // delta
-                    c[20] = a35; c[21] = 0.0; c[22] = 1.0; c[23] = 0.0;    // thr
-                    double *u = ct + C_UNIT;
+                    double *c = ct + G_XY;          // rows v,delta,thr in the (X,Y,psi) positions of each group
+                    c[0 * GS] = 0.0; c[0 * GS + 1] = h;   c[0 * GS + 2] = 0.0;     // u0
+                    c[1 * GS] = b31; c[1 * GS + 1] = 0.0; c[1 * GS + 2] = h;       // u1
+                    c[2 * GS] = 0.0; c[2 * GS + 1] = 0.0; c[2 * GS + 2] = 0.0;     // psi
+                    c[3 * GS] = a33; c[3 * GS + 1] = 0.0; c[3 * GS + 2] = 0.0;     // v
+                    c[4 * GS] = 0.0; c[4 * GS + 1] = 1.0; c[4 * GS + 2] = 0.0;     // delta
+                    c[5 * GS] = a35; c[5 * GS + 1] = 0.0; c[5 * GS + 2] = 1.0;     // thr
+                    double *u = xa + X_UNIT;
                     u[0] = 1.0; u[1] = 0.0; u[2] = 0.0; u[3] = 0.0; u[4] = 0.0; u[5] = 1.0; u[6] = 0.0; u[7] = 0.0;
-                    double *zz = ct + C_ZERO;
+                    double *zz = xa + X_ZERO;
                     zz[0] = 0.0; zz[1] = 0.0; zz[2] = 0.0; zz[3] = 0.0;
+                    double *ft = xa + X_FT;
+                    ft[0] = 1.0; ft[1] = 0.0; ft[2] = 0.0; ft[3] = 0.0; ft[4] = 1.0; ft[5] = 0.0;
                     double *e = xa + X_HU + 18;     // unit columns: the lanes reading them get -inv(Huu)
                     e[0] = 1.0; e[1] = 0.0; e[2] = 0.0; e[3] = 1.0;
                 }
@@ -377,10 +395,10 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     double *sl = stg + tid * ST;
                     // 16-byte stores: with the stage stride of 100 dwords they are bank-conflict free
                     // across lanes (8-byte accesses are 2-way)
-                    st2(sl + O_TAB + 0, gam[0], gam[1]); st2(sl + O_TAB + 2, gam[2], gam[3]);
-                    st2(sl + O_TAB + 4, Q00, Q01);       st2(sl + O_TAB + 6, Q02, 0.0);
+                    st2(sl + I_GAM01, gam[0], gam[1]); st2(sl + I_GAM23, gam[2], gam[3]);
+                    st2(sl + I_Q0, Q00, Q01);          st2(sl + I_Q2, Q02, 0.0);
 #pragma unroll
-                    for (int m = 0; m < 8; m += 2) st2(sl + O_G + m, G[m], G[m + 1]);
+                    for (int m = 0; m < 8; m += 2) st2(sl + I_G + m, G[m], G[m + 1]);
                     st2(sl + O_D + 0, rb[0], rb[1]); st2(sl + O_D + 2, rb[2], 0.0);
                     st2(sl + O_D + 4, rb[3], rb[4]); st2(sl + O_D + 6, rb[5], 0.0);
                 }
@@ -412,36 +430,36 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 const double *tj, *bj;
                 int sTopJ, sBotJ;
                 if (f1j == 8) { tj = last + O_D; bj = last + O_D + 4; sTopJ = ST; sBotJ = ST; }
-                else if (f1j == 2 || f1j == 3) { tj = ct + C_UNIT + 4 * (f1j - 2); bj = ct + C_ZERO; sTopJ = 0; sBotJ = 0; }
-                else { tj = last + O_BA + 4 * NMPC_VCOL(f1j); bj = ct + C_BOT + 4 * NMPC_VCOL(f1j); sTopJ = ST; sBotJ = 0; }
+                else if (f1j == 2 || f1j == 3) { tj = xa + X_UNIT + 4 * (f1j - 2); bj = xa + X_ZERO; sTopJ = 0; sBotJ = 0; }
+                else { tj = last + GS * NMPC_VCOL(f1j) + G_XY; bj = ct + GS * NMPC_VCOL(f1j) + G_XY; sTopJ = ST; sBotJ = 0; }
                 // column i of BAt for phase 2 (i < 8)
                 const double *ti, *pBotI;
                 int sTopI;
-                if (f2i == 2 || f2i == 3) { ti = ct + C_UNIT + 4 * (f2i - 2); pBotI = ct + C_ZERO; sTopI = 0; }
-                else { ti = last + O_BA + 4 * NMPC_VCOL(f2i); pBotI = ct + C_BOT + 4 * NMPC_VCOL(f2i); sTopI = ST; }
+                if (f2i == 2 || f2i == 3) { ti = xa + X_UNIT + 4 * (f2i - 2); pBotI = xa + X_ZERO; sTopI = 0; }
+                else { ti = last + GS * NMPC_VCOL(f2i) + G_XY; pBotI = ct + GS * NMPC_VCOL(f2i) + G_XY; sTopI = ST; }
                 const double e8 = (f1j == 8) ? 1.0 : 0.0;
                 const double *const pProw = xa + X_P + f1m * 8;
                 double *const pMw = fl < 54 ? xa + X_M + f1j * 6 + f1m : xa + X_DUM;
                 const double *const pMr = xa + X_M + f2j * 6;
                 // cost part of Ht[i][j]: a constant plus (at most) one per-stage table entry
                 double hconst = 0.0;
-                const double *tb = ct + C_ZERO;
+                const double *tb = xa + X_ZERO;
                 int sTab = 0;
                 {
                     int off = -1;
-                    if (f2j == 8) off = (O_G - O_TAB) + f2i;                 // gradient column
+                    if (f2j == 8) off = I_G + f2i;                           // gradient column
                     else if (f2i == f2j) {
-                        if (f2i == 0) { hconst = R00; off = 0; }
-                        if (f2i == 1) { hconst = R11; off = 1; }
-                        if (f2i == 2) off = 4;
+                        if (f2i == 0) { hconst = R00; off = I_GAM01; }
+                        if (f2i == 1) { hconst = R11; off = I_GAM01 + 1; }
+                        if (f2i == 2) off = I_Q0;
                         if (f2i == 3) hconst = Q11;
                         if (f2i == 4) hconst = Q22;
                         if (f2i == 5) hconst = Q33;
-                        if (f2i == 6) { hconst = Q44; off = 2; }
-                        if (f2i == 7) { hconst = Q55; off = 3; }
-                    } else if (f2i == 2 && f2j == 3) off = 5;
-                    else if (f2i == 2 && f2j == 4) off = 6;
-                    if (off >= 0) { tb = last + O_TAB + off; sTab = ST; }
+                        if (f2i == 6) { hconst = Q44; off = I_GAM23; }
+                        if (f2i == 7) { hconst = Q55; off = I_GAM23 + 1; }
+                    } else if (f2i == 2 && f2j == 3) off = I_Q0 + 1;
+                    else if (f2i == 2 && f2j == 4) off = I_Q2;
+                    if (off >= 0) { tb = last + off; sTab = ST; }
                 }
                 // phase 2 store of the two input rows (pairs (Ht[0][j], Ht[1][j])), phase 3 loads/stores
                 double *const pHw = (f2on && f2i < 2) ? xa + X_HU + 2 * f2j + f2i : xa + X_DUM;
@@ -452,7 +470,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 if (f2on && f2i >= 2) {
                     pPw1 = xa + X_P + (f2i - 2) * 8 + (f2j - 2);
                     if (f2j <= 7) pPw2 = xa + X_P + (f2j - 2) * 8 + (f2i - 2);
-                    if (f2i == 2) { kw = last + O_KP + 2 * (f2j - 2); sKw = ST; }
+                    if (f2i == 2) { kw = last + NMPC_KOFF(f2j - 2); sKw = ST; }
                 }
                 if (fl == 44 || fl == 45) { kw = last + O_INV + 2 * (fl - 44); sKw = ST; }
 #pragma unroll 1
@@ -504,87 +522,91 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
 #pragma unroll 1
             for (int pass = 0; pass < 2; ++pass) {
                 if (w.sweep_wave() && pass == 1) {
-                    // backward vector sweep (corrector right-hand side, homogeneous dynamics): lane vl
-                    // owns z component vl, the recursion vector p is wave-uniform (re-gathered with
-                    // readlane: no LDS round trip on the serial path)
+                    // backward vector sweep (corrector right-hand side, homogeneous dynamics).  Lane
+                    // vl = lane & 7 owns z component vl; the result of a stage (lanes 0,1: kff, lanes
+                    // 2..7: the costate p) feeds the next stage through fmac_row, the fp64 multiply-add
+                    // whose first factor is another lane of the same 16-lane row: the serial path has
+                    // neither an LDS round trip nor a v_readlane.
                     const int bl = w.opaque(lane);
                     const int vl = bl & 7;
                     const double *tv;                 // column vl of [B A], rows X,Y,psi
                     int sTopV;
-                    if (vl == 2 || vl == 3) { tv = ct + C_UNIT + 4 * (vl - 2); sTopV = 0; }
-                    else { tv = last + O_BA + 4 * NMPC_VCOL(vl); sTopV = ST; }
-                    const double *dg = ct + C_ZERO;   // corrector gradient entry of component vl
+                    if (vl == 2 || vl == 3) { tv = xa + X_UNIT + 4 * (vl - 2); sTopV = 0; }
+                    else { tv = last + GS * NMPC_VCOL(vl) + G_XY; sTopV = ST; }
+                    const double *dg = xa + X_ZERO;   // corrector gradient entry of component vl
                     int sDgV = 0;
                     if (vl < 2) { dg = last + O_D + vl; sDgV = ST; }
                     if (vl >= 6) { dg = last + O_D + vl - 4; sDgV = ST; }
-                    // res = keep * hc + ab.x * hu0 + ab.y * hu1: lanes >= 2 form p_new with their gain
+                    // res = keep * hc + ab.x * hc[0] + ab.y * hc[1]: lanes >= 2 form p_new with their gain
                     // pair (K0,K1); lanes 0,1 form kff = -(inv hu) with row vl of -inv
-                    const double *ab = vl >= 2 ? last + O_KP + 2 * (vl - 2) : last + O_INV + 2 * vl;
+                    const double *ab = vl >= 2 ? last + NMPC_KOFF(vl - 2) : last + O_INV + 2 * vl;
                     const double keep = vl >= 2 ? 1.0 : 0.0;
-                    double *kfw = bl < 2 ? last + O_KP + 12 + bl : xa + X_DUM;
+                    double *kfw = bl < 2 ? last + O_E + 4 + bl : xa + X_DUM;
                     const int sKfw = bl < 2 ? ST : 0;
                     // rows v,delta,thr of column vl
                     const double cb0 = vl == 1 ? b31 : vl == 5 ? a33 : vl == 7 ? a35 : 0.0;
                     const double cb1 = vl == 0 ? h : vl == 6 ? 1.0 : 0.0;
                     const double cb2 = vl == 1 ? h : vl == 7 ? 1.0 : 0.0;
-                    double p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0;
+                    // stage data is fetched one stage ahead (two register sets, loop unrolled twice): the
+                    // LDS latency then hides behind the multiply-add chain of the current stage
+                    double res = 0.0;
+                    double da[6], db[6];      // column (X,Y,psi), gradient entry, gain pair
+                    w.bwd_fetch(tv, dg, ab, da);
 #pragma unroll 1
-                    for (int k = (NMPC_PROF_SKIP & 2) ? -1 : N - 1; k >= 0; --k) {
-                        const D2 t01 = ld2(tv), kab = ld2(ab);
-                        const double t2 = tv[2], dgv = *dg;
-                        w.sched_fence();
-                        double hA = fma(t01.x, p0, dgv), hB = t01.y * p1;
-                        hA = fma(t2, p2, hA); hB = fma(cb0, p3, hB);
-                        hA = fma(cb1, p4, hA); hB = fma(cb2, p5, hB);
-                        const double hc = hA + hB;
-                        const double hu0 = w.readlane(hc, 0), hu1 = w.readlane(hc, 1);
-                        const double res = fma(kab.y, hu1, fma(kab.x, hu0, keep * hc));
-                        *kfw = res;
-                        p0 = w.readlane(res, 2); p1 = w.readlane(res, 3); p2 = w.readlane(res, 4);
-                        p3 = w.readlane(res, 5); p4 = w.readlane(res, 6); p5 = w.readlane(res, 7);
-                        tv -= sTopV; dg -= sDgV; ab -= ST; kfw -= sKfw;
+                    for (int k = (NMPC_PROF_SKIP & 2) ? -1 : N - 1; k >= 0; k -= 2) {
+                        tv -= sTopV; dg -= sDgV; ab -= ST;
+                        w.bwd_stage(da, db, tv, dg, ab, kfw, cb0, cb1, cb2, keep, res);
+                        kfw -= sKfw;
+                        if (k == 0) break;
+                        tv -= sTopV; dg -= sDgV; ab -= ST;
+                        w.bwd_stage(db, da, tv, dg, ab, kfw, cb0, cb1, cb2, keep, res);
+                        kfw -= sKfw;
                     }
                     w.wsync();
                 }
-                // forward sweep: lane vl computes row vr of dx+ and input (vl & 1); z_k is stored in
-                // slot k-1 (its r_b has been consumed), dx is wave-uniform
+                // forward sweep.  Lanes 0..5 of every 16-lane row own a row of dx_{k+1}, lanes 6,7 own
+                // du_k[0], du_k[1] (lanes 8..15 repeat 0..7); dx_k sits in lanes 0..5 and reaches the
+                // others through fmac_row.  Level 1: every lane starts from r_b / kff and adds its six
+                // coefficients (row of A, or row of K) times dx_k; level 2: the state rows add their
+                // B entries times du (lanes 6,7 read zeros there and keep du).  z_k is stored in slot
+                // k-1 (its r_b has been consumed).
                 if (w.sweep_wave()) {
-                    const double rbs = pass == 0 ? 1.0 : 0.0;
                     const int fl = w.opaque(lane);
                     const int vl = fl & 7;
-                    const int vr = vl < 6 ? vl : 5;     // lanes 6,7 duplicate row 5
-                    const double *rw = vr < 3 ? stg + O_BA + vr : ct + C_BOT + (vr - 3);
-                    const int sRowV = vr < 3 ? ST : 0;
-                    const double eX = vr == 0 ? 1.0 : 0.0, eY = vr == 1 ? 1.0 : 0.0;
-                    const double *kr = stg + O_KP + (vl & 1);     // K_a[c] at kr[2c], kff_a at kr[12]
-                    const double *rbp = stg + O_D + (vr < 3 ? vr : vr + 1);
-                    double *dnw = stg + O_D + 2 + vr;             // dx_{k+1}[vr] -> slot k
-                    double *duw = fl < 2 ? ct + O_D + fl : xa + X_DUM;   // du_k[a] -> slot k-1
-                    const int sDuw = fl < 2 ? ST : 0;
-                    double x0 = 0, x1 = 0, x2 = 0, x3 = 0, x4 = 0, x5 = 0;
+                    // six coefficients at group spacing: columns u0,u1 (level 2) and psi,v,delta,thr
+                    const double *p1;
+                    int s1;
+                    if (vl < 3) { p1 = stg + G_XY + vl; s1 = ST; }                 // rows X,Y,psi of [B A]
+                    else if (vl < 6) { p1 = ct + G_XY + (vl - 3); s1 = 0; }        // rows v,delta,thr: constants
+                    else { p1 = stg + G_K + (vl - 6); s1 = ST; }                   // K_a[psi..thr], zeros for u0,u1
+                    // coefficients of dx_X, dx_Y: unit columns for the state rows, K_a[X], K_a[Y] for the inputs
+                    const double *p3;
+                    int s3;
+                    if (vl < 6) { p3 = xa + X_FT + (vl == 0 ? 0 : vl == 1 ? 2 : 1); s3 = 0; }
+                    else { p3 = stg + O_E + (vl - 6); s3 = ST; }
+                    // start value: r_b (affine pass only) or kff
+                    const double *p2;
+                    int s2;
+                    if (vl >= 6) { p2 = stg + O_E + 4 + (vl - 6); s2 = ST; }
+                    else if (pass == 0) { p2 = stg + O_D + (vl < 3 ? vl : vl + 1); s2 = ST; }
+                    else { p2 = xa + X_ZERO; s2 = 0; }
+                    double *sw = xa + X_DUM;          // dx_{k+1}[r] -> slot k, du_k[a] -> slot k-1
+                    int sSw = 0;
+                    if (fl < 6) { sw = stg + O_D + 2 + fl; sSw = ST; }
+                    else if (fl < 8) { sw = ct + O_D + (fl - 6); sSw = ST; }
+                    // coefficients are fetched one stage ahead, as in the backward sweep
+                    double val = 0.0;
+                    double fa[9], fb[9];      // six group-spaced coefficients, two for dx_X, dx_Y, start value
+                    w.fwd_fetch(p1, p3, p2, fa);
 #pragma unroll 1
-                    for (int k = (NMPC_PROF_SKIP & 4) ? N : 0; k < N; ++k) {
-                        // 14 single 8-byte loads, strided: kept as ds_read_b64 (the pairs the compiler would
-                        // merge them into cost 4x the LDS cycles)
-                        double kk[7], rr[6], rbv;
-                        w.lds_gather_fwd(kr, rw, rbp, kk, rr, &rbv);
-                        const double k0 = kk[0], k1 = kk[1], k2 = kk[2], k3 = kk[3], k4 = kk[4], k5 = kk[5], kf = kk[6];
-                        const double b0 = rr[0], b1 = rr[1], a2 = rr[2], a3 = rr[3], a4 = rr[4], a5 = rr[5];
-                        w.sched_fence();
-                        double uA = fma(k0, x0, kf), uB = k1 * x1;
-                        uA = fma(k2, x2, uA); uB = fma(k3, x3, uB);
-                        uA = fma(k4, x4, uA); uB = fma(k5, x5, uB);
-                        const double dua = uA + uB;
-                        double rA = fma(eX, x0, rbs * rbv), rB = eY * x1;
-                        rA = fma(a2, x2, rA); rB = fma(a3, x3, rB);
-                        rA = fma(a4, x4, rA); rB = fma(a5, x5, rB);
-                        const double du0 = w.readlane(dua, 0), du1 = w.readlane(dua, 1);
-                        const double dn = fma(b1, du1, fma(b0, du0, rA + rB));
-                        *dnw = dn;
-                        *duw = dua;
-                        x0 = w.readlane(dn, 0); x1 = w.readlane(dn, 1); x2 = w.readlane(dn, 2);
-                        x3 = w.readlane(dn, 3); x4 = w.readlane(dn, 4); x5 = w.readlane(dn, 5);
-                        rw += sRowV; kr += ST; rbp += ST; dnw += ST; duw += sDuw;
+                    for (int k = (NMPC_PROF_SKIP & 4) ? N : 0; k < N; k += 2) {
+                        p1 += s1; p2 += s2; p3 += s3;
+                        w.fwd_stage(fa, fb, p1, p3, p2, sw, val);
+                        sw += sSw;
+                        if (k + 1 == N) break;
+                        p1 += s1; p2 += s2; p3 += s3;
+                        w.fwd_stage(fb, fa, p1, p3, p2, sw, val);
+                        sw += sSw;
                     }
                     if (lane == 0) {                // z_0 = (du_0, 0): dx_0 is folded into r_b
 #pragma unroll
@@ -739,5 +761,6 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
 
 #undef NMPC_ZQ
 #undef NMPC_VCOL
+#undef NMPC_KOFF
 
 }  // namespace nmpcw

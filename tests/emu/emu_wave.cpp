@@ -83,12 +83,59 @@ struct EmuWave {
     double *lds() { return g_s->lds; }
     int opaque(int v) { return v; }
     void sched_fence() {}
-    void lds_gather_fwd(const double *kr, const double *rw, const double *rbp, double (&kk)[7],
-                        double (&rr)[6], double *rbv)
+    void fwd_fetch(const double *p1, const double *p3, const double *p2, double (&d)[9])
     {
-        for (int c = 0; c < 7; ++c) kk[c] = kr[2 * c];
-        for (int c = 0; c < 6; ++c) rr[c] = rw[4 * c];
-        *rbv = *rbp;
+        for (int c = 0; c < 6; ++c) d[c] = p1[nmpcw::GS * c];
+        d[6] = p3[0];
+        d[7] = p3[2];
+        d[8] = *p2;
+    }
+    // one forward-sweep stage on the data in `cur` while `nxt` is fetched from the next stage
+    void fwd_stage(double (&cur)[9], double (&nxt)[9], const double *p1, const double *p3, const double *p2,
+                   double *sw, double &val)
+    {
+        fwd_fetch(p1, p3, p2, nxt);
+        double vA = fmac_row<0>(cur[8], val, cur[6]);
+        double vB = fmac_row<1>(0.0, val, cur[7]);
+        vA = fmac_row<2>(vA, val, cur[2]);
+        vB = fmac_row<3>(vB, val, cur[3]);
+        vA = fmac_row<4>(vA, val, cur[4]);
+        vB = fmac_row<5>(vB, val, cur[5]);
+        val = vA + vB;
+        val = fmac_row<6>(val, val, cur[0]);
+        val = fmac_row<7>(val, val, cur[1]);
+        *sw = val;
+    }
+    void bwd_fetch(const double *tv, const double *dg, const double *ab, double (&d)[6])
+    {
+        d[0] = tv[0]; d[1] = tv[1]; d[2] = tv[2];
+        d[3] = *dg;
+        d[4] = ab[0]; d[5] = ab[1];
+    }
+    void bwd_stage(double (&cur)[6], double (&nxt)[6], const double *tv, const double *dg, const double *ab,
+                   double *kfw, double cb0, double cb1, double cb2, double keep, double &res)
+    {
+        bwd_fetch(tv, dg, ab, nxt);
+        double hA = fmac_row<2>(cur[3], res, cur[0]);
+        double hB = fmac_row<3>(0.0, res, cur[1]);
+        hA = fmac_row<4>(hA, res, cur[2]);
+        hB = fmac_row<5>(hB, res, cb0);
+        hA = fmac_row<6>(hA, res, cb1);
+        hB = fmac_row<7>(hB, res, cb2);
+        const double hc = hA + hB;
+        res = keep * hc;
+        res = fmac_row<0>(res, hc, cur[4]);
+        res = fmac_row<1>(res, hc, cur[5]);
+        *kfw = res;
+    }
+    template <int C>
+    double fmac_row(double acc, double src, double coef)   // lane C of the caller's 16-lane row
+    {
+        g_s->tmp[tid_] = src;
+        wsync();
+        const double r = fma(g_s->tmp[(tid_ & ~15) + C], coef, acc);
+        wsync();
+        return r;
     }
     void sync() { barrier(g_s->wg, g_s->nt, tid_); }
     void wsync() { barrier(g_s->wave[tid_ / WAVE], WAVE, tid_); }

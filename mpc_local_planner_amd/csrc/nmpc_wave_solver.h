@@ -473,14 +473,17 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     if (f2i == 2) { kw = last + NMPC_KOFF(f2j - 2); sKw = ST; }
                 }
                 if (fl == 44 || fl == 45) { kw = last + O_INV + 2 * (fl - 44); sKw = ST; }
-#pragma unroll 1
+                // rows v,delta,thr of column i are constants: loaded once per sweep
+                const D2 v01 = ld2(pBotI);
+                const double v2 = pBotI[2];
+                // stage data (independent of the recursion) is fetched one stage ahead, so that the
+                // loads that ARE on the serial path (Pt row, Mt column, input rows) never queue behind it
+                D2 t01 = ld2(tj), b01 = ld2(bj), u01 = ld2(ti);
+                double t2 = tj[2], b2 = bj[2], u2 = ti[2], tbv = *tb;
+#pragma unroll 2
                 for (int k = (NMPC_PROF_SKIP & 1) ? -1 : N - 1; k >= 0; --k) {
-                    // stage data of phases 1 and 2 (independent of the recursion) and the Pt row
-                    const D2 t01 = ld2(tj), b01 = ld2(bj), u01 = ld2(ti), v01 = ld2(pBotI);
-                    const double t2 = tj[2], b2 = bj[2], u2 = ti[2], v2 = pBotI[2];
                     const D2 r01 = ld2(pProw), r23 = ld2(pProw + 2), r45 = ld2(pProw + 4);
                     const double r6 = pProw[6];
-                    const double hc = hconst + *tb;
                     w.sched_fence();
                     // phase 1: Mt[m][j] = Pt[m][0..5] . BAt[0..5][j] + p[m] [j == 8]
                     double accA = r6 * e8, accB = r01.y * t01.y;
@@ -491,18 +494,23 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     w.wsync();
                     // phase 2: Ht[i][j] = cost[i][j] + BAt[0..5][i] . Mt[0..5][j]
                     const D2 m01 = ld2(pMr), m23 = ld2(pMr + 2), m45 = ld2(pMr + 4);
+                    // data of stage k-1 (at k = 0 this reads the pseudo-stage: valid memory, not used)
+                    tj -= sTopJ; bj -= sBotJ; ti -= sTopI; tb -= sTab;
+                    const D2 nt01 = ld2(tj), nb01 = ld2(bj), nu01 = ld2(ti);
+                    const double nt2 = tj[2], nb2 = bj[2], nu2 = ti[2], ntb = *tb;
                     w.sched_fence();
-                    double HvA = fma(u01.x, m01.x, hc), HvB = u01.y * m01.y;
+                    double HvA = fma(u01.x, m01.x, hconst + tbv), HvB = u01.y * m01.y;
                     HvA = fma(u2, m23.x, HvA);    HvB = fma(v01.x, m23.y, HvB);
                     HvA = fma(v01.y, m45.x, HvA); HvB = fma(v2, m45.y, HvB);
                     const double Hv = HvA + HvB;
                     *pHw = Hv;
+                    // the 2x2 input block straight from its lanes (0: H00, 1: H01, 9: H11): its inverse is
+                    // worked out while the input rows make their way through LDS
+                    const double H00 = w.readlane(Hv, 0), H01 = w.readlane(Hv, 1), H11 = w.readlane(Hv, 9);
                     w.wsync();
                     // phase 3: eliminate the inputs
-                    const D2 hu0 = ld2(xa + X_HU), hu1 = ld2(xa + X_HU + 2);   // (H00,-), (H01,H11)
                     const D2 hj = ld2(pHj), hi = ld2(pHi);
                     w.sched_fence();
-                    const double H00 = hu0.x, H01 = hu1.x, H11 = hu1.y;
                     const double rdet = w.rcp(H00 * H11 - H01 * H01);
                     const double i00 = H11 * rdet, i01 = -H01 * rdet, i11 = H00 * rdet;
                     const double K0 = -(i00 * hj.x + i01 * hj.y), K1 = -(i01 * hj.x + i11 * hj.y);
@@ -511,7 +519,8 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     *pPw2 = Pn;
                     st2(kw, K0, K1);
                     w.wsync();
-                    tj -= sTopJ; bj -= sBotJ; ti -= sTopI; tb -= sTab; kw -= sKw;
+                    kw -= sKw;
+                    t01 = nt01; b01 = nb01; u01 = nu01; t2 = nt2; b2 = nb2; u2 = nu2; tbv = ntb;
                 }
             }
 

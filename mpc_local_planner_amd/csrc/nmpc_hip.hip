@@ -54,7 +54,10 @@ struct GpuWave {
     // row, so the recursion vector never leaves the VALU.  Hand-written because (a) the compiler
     // merges the strided 8-byte loads into ds_read2_b64 (8 LDS cycles per pair instead of 2+2),
     // (b) it does not fold a 64-bit DPP move into the multiply-add, (c) a load that is waited for
-    // in a later statement is not something C++ can express.  Every register the chain reads
+    // in a later statement is not something C++ can express.  The closing wait leaves the stage's own
+    // store in flight (LDS operations of a wave complete in order, so lgkmcnt(1) covers the loads); the
+    // compiler's later waits are only more conservative for it, and sweep_drain() ends each sweep.
+    // Every register the chain reads
     // through DPP is written by an fp64 VALU instruction at least one instruction earlier
     // (tools/micro/dpp_latency.hip: the dependent issue distance of fp64 covers the DPP wait states).
     static __device__ __forceinline__ unsigned lds_addr(const double *p)
@@ -108,7 +111,7 @@ struct GpuWave {
             "s_nop 0\n\t"
             "v_fmac_f64_dpp %[val], %[val], %[c1] row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
             "ds_write_b64 %[sw], %[val]\n\t"
-            "s_waitcnt lgkmcnt(0)"
+            "s_waitcnt lgkmcnt(1)"
             : [n0] "=&v"(nxt[0]), [n1] "=&v"(nxt[1]), [n2] "=&v"(nxt[2]), [n3] "=&v"(nxt[3]), [n4] "=&v"(nxt[4]),
               [n5] "=&v"(nxt[5]), [n6] "=&v"(nxt[6]), [n7] "=&v"(nxt[7]), [n8] "=&v"(nxt[8]), [t] "=&v"(t),
               [val] "+v"(val), [iv] "+v"(cur[8])
@@ -156,7 +159,7 @@ struct GpuWave {
             "v_fmac_f64_dpp %[res], %[g], %[ka] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %[res], %[g], %[kb] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
             "ds_write_b64 %[kfw], %[res]\n\t"
-            "s_waitcnt lgkmcnt(0)"
+            "s_waitcnt lgkmcnt(1)"
             : [n0] "=&v"(nxt[0]), [n1] "=&v"(nxt[1]), [n2] "=&v"(nxt[2]), [n3] "=&v"(nxt[3]), [n4] "=&v"(nxt[4]),
               [n5] "=&v"(nxt[5]), [t] "=&v"(t), [res] "+v"(res), [g] "+v"(cur[3])
             : [t0] "v"(cur[0]), [t1] "v"(cur[1]), [t2] "v"(cur[2]), [ka] "v"(cur[4]), [kb] "v"(cur[5]),
@@ -164,6 +167,8 @@ struct GpuWave {
               [adg] "v"(lds_addr(dg)), [aab] "v"(lds_addr(ab)), [kfw] "v"(lds_addr(kfw))
             : "memory");
     }
+    // after a sweep: nothing of it is still in flight
+    __device__ __forceinline__ void sweep_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     // acc + (src of lane C of the caller's 16-lane row) * coef, fused (single use outside the sweeps' asm)
     template <int C>
     __device__ __forceinline__ double fmac_row(double acc, double src, double coef)

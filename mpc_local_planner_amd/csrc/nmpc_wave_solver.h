@@ -571,6 +571,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                         w.bwd_stage(db, da, tv, dg, ab, kfw, cb0, cb1, cb2, keep, res);
                         kfw -= sKfw;
                     }
+                    w.sweep_drain();
                     w.wsync();
                 }
                 // forward sweep.  Lanes 0..5 of every 16-lane row own a row of dx_{k+1}, lanes 6,7 own
@@ -617,6 +618,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                         w.fwd_stage(fb, fa, p1, p3, p2, sw, val);
                         sw += sSw;
                     }
+                    w.sweep_drain();
                     if (lane == 0) {                // z_0 = (du_0, 0): dx_0 is folded into r_b
 #pragma unroll
                         for (int m = 0; m < 6; ++m) ct[O_D + 2 + m] = 0.0;

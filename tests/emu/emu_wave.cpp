@@ -106,6 +106,7 @@ struct EmuWave {
         val = fmac_row<7>(val, val, cur[1]);
         *sw = val;
     }
+    void sweep_drain() {}
     void bwd_fetch(const double *tv, const double *dg, const double *ab, double (&d)[6])
     {
         d[0] = tv[0]; d[1] = tv[1]; d[2] = tv[2];

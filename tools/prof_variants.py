@@ -4,7 +4,7 @@ nmpc_wave_solver.h (fixed interior-point iteration count, sweeps left out) into
 build_variants/, so that one gpurun call can time them side by side:
 
     python tools/prof_variants.py build
-    gpurun -- python tools/prof_variants.py run
+    gpurun -- python tools/prof_variants.py run [batch]
 
 Results of the skip variants are numerically meaningless; only kernel time differences matter.
 """
@@ -35,12 +35,13 @@ def build():
         print("built", lib)
 
 
-def run():
+def run(batch="4096"):
     res = {}
     for name in VARIANTS:
         env = dict(os.environ, NMPC_HIP_LIB=os.path.join(OUT, f"libnmpc_{name}.so"))
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "20",
-                              "--warmup", "3"], env=env, capture_output=True, text=True, timeout=200)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extras",
+                              "--steps", "20", "--warmup", "3", "--batch", batch], env=env, capture_output=True,
+                             text=True, timeout=200)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1])
             res[name] = d["roofline"]["kernel_ms"]
@@ -48,8 +49,8 @@ def run():
             res[name] = out.stderr[-300:]
         print(name, res[name], flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "prof_variants.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(ROOT, "gpurun_out", f"prof_variants_{batch}.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
-    {"build": build, "run": run}[sys.argv[1]]()
+    {"build": build, "run": run}[sys.argv[1]](*sys.argv[2:])

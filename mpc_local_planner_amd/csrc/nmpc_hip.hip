@@ -57,9 +57,9 @@ struct GpuWave {
     // in a later statement is not something C++ can express.  The closing wait leaves the stage's own
     // store in flight (LDS operations of a wave complete in order, so lgkmcnt(1) covers the loads); the
     // compiler's later waits are only more conservative for it, and sweep_drain() ends each sweep.
-    // Every register the chain reads
-    // through DPP is written by an fp64 VALU instruction at least one instruction earlier
-    // (tools/micro/dpp_latency.hip: the dependent issue distance of fp64 covers the DPP wait states).
+    // A register read through DPP needs two wait states after the VALU write of it (the hardware
+    // does not interlock: a build without them failed tests/test_gpu_cpp_mirror.py); the compiler
+    // cannot see into the asm, so each chain provides them itself (an independent instruction + s_nop 0).
     static __device__ __forceinline__ unsigned lds_addr(const double *p)
     {
         typedef __attribute__((address_space(3))) const double lds_cd;
@@ -105,12 +105,12 @@ struct GpuWave {
             "v_fmac_f64_dpp %[t], %[val], %[c3] row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %[iv], %[val], %[c4] row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %[t], %[val], %[c5] row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-            "v_add_f64 %[val], %[iv], %[t]\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64_dpp %[val], %[val], %[c0] row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-            "s_nop 0\n\t"
-            "v_fmac_f64_dpp %[val], %[val], %[c1] row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-            "ds_write_b64 %[sw], %[val]\n\t"
+            "v_add_f64 %[val], %[iv], %[t]\n\t"     // level-1 result: what the two DPP reads below take
+            "v_add_f64 %[t], %[iv], %[t]\n\t"       // the same sum again as the accumulator: with the s_nop
+            "s_nop 0\n\t"                           // that is the two wait states between write and DPP read
+            "v_fmac_f64_dpp %[t], %[val], %[c0] row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[t], %[val], %[c1] row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+            "ds_write_b64 %[sw], %[t]\n\t"
             "s_waitcnt lgkmcnt(1)"
             : [n0] "=&v"(nxt[0]), [n1] "=&v"(nxt[1]), [n2] "=&v"(nxt[2]), [n3] "=&v"(nxt[3]), [n4] "=&v"(nxt[4]),
               [n5] "=&v"(nxt[5]), [n6] "=&v"(nxt[6]), [n7] "=&v"(nxt[7]), [n8] "=&v"(nxt[8]), [t] "=&v"(t),
@@ -118,7 +118,7 @@ struct GpuWave {
             : [c0] "v"(cur[0]), [c1] "v"(cur[1]), [c2] "v"(cur[2]), [c3] "v"(cur[3]), [c4] "v"(cur[4]),
               [c5] "v"(cur[5]), [e0] "v"(cur[6]), [e1] "v"(cur[7]), [a1] "v"(lds_addr(p1)), [a3] "v"(lds_addr(p3)),
               [a2] "v"(lds_addr(p2)), [sw] "v"(lds_addr(sw))
-            : "memory");
+            : "memory");        val = t;
     }
     // d[0..2] = tv[0..2], d[3] = dg[0], d[4,5] = ab[0,1]
     __device__ __forceinline__ void bwd_fetch(const double *tv, const double *dg, const double *ab, double (&d)[6])
@@ -156,6 +156,7 @@ struct GpuWave {
             "v_fmac_f64_dpp %[t], %[res], %[cb2] row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
             "v_add_f64 %[g], %[g], %[t]\n\t"
             "v_mul_f64 %[res], %[keep], %[g]\n\t"
+            "s_nop 0\n\t"
             "v_fmac_f64_dpp %[res], %[g], %[ka] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %[res], %[g], %[kb] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
             "ds_write_b64 %[kfw], %[res]\n\t"

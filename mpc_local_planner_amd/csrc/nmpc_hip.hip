@@ -241,14 +241,14 @@ struct GpuWave {
         const double s = fmax(fmax(readlane(v, 0), readlane(v, 16)), fmax(readlane(v, 32), readlane(v, 48)));
         return across_waves(s, [](double a, double b) { return fmax(a, b); });
     }
-    // reciprocal to ~1 ulp: hardware seed + two Newton steps (no div_scale/div_fixup sequence;
-    // operands here are never subnormal or huge)
+    // reciprocal to ~1 ulp: hardware seed y (relative error e ~ 5e-8, tools/micro/rcp_accuracy.hip) times
+    // 1 + e + e^2 (error e^3) -- three dependent multiply-adds where two Newton steps take four; no
+    // div_scale/div_fixup sequence, operands here are never subnormal or huge
     __device__ __forceinline__ double rcp(double x)
     {
-        double y = __builtin_amdgcn_rcp(x);
-        y = fma(fma(-x, y, 1.0), y, y);
-        y = fma(fma(-x, y, 1.0), y, y);
-        return y;
+        const double y = __builtin_amdgcn_rcp(x);
+        const double e = fma(-x, y, 1.0);
+        return fma(y, fma(e, e, e), y);
     }
 };
 

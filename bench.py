@@ -26,10 +26,21 @@ sys.path.insert(0, ROOT)
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # = 1/2 of the 157.3 TF fp32 vector spec (MI355X_MICROARCH.md); also the fp64 MFMA peak
 HBM_PEAK_GBPS = 8000.0
-# HBM bytes per 4096-instance launch from the PMC passes committed under profiles/r1c/ (rocprofv3
+# HBM bytes per 4096-instance launch come from the PMC passes committed under profiles/ (rocprofv3
 # cannot be read from inside this process): 2 x FETCH_SIZE (gfx950 tallies 128-B requests as 64 B;
-# the factor is calibrated for wide streaming reads only, so this is an upper bound) + WRITE_SIZE.
-PMC_TRAFFIC_BYTES_PER_LAUNCH_B4096_N40 = int((2 * 23968.8 + 86094.4) * 1024)
+# the factor is calibrated for wide streaming reads only, so this is an upper bound) + WRITE_SIZE,
+# both in KiB as rocprofv3 reports them.
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1d", "pmc_summary.json")
+
+
+def pmc_traffic_bytes_per_launch():
+    """Measured HBM bytes of one B = 4096, N = 40 launch of nmpc_solve_kernel, or None."""
+    try:
+        with open(PMC_SUMMARY) as f:
+            d = json.load(f)
+        return int((2.0 * d["FETCH_SIZE"]["mean_per_launch"] + d["WRITE_SIZE"]["mean_per_launch"]) * 1024)
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def flops_per_solve(N, n_ipm):
@@ -267,11 +278,13 @@ def main():
         by = bytes_per_solve(N, False) * B
         tf = fl / (kernel_ms * 1e-3) / 1e12
         out["roofline"] = {
-            "bound": "fp64_valu", "kernel": "nmpc_solve_kernel", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS,
+            "bound": "mfma", "kernel": "nmpc_solve_kernel", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
-            "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH_B4096_N40 if (B == 4096 and N == 40) else None,
-            "note": "fp64 vector FMA rate (no MFMA-shaped work; the fp64 MFMA peak is the same 78.6 TF); measured "
-                    "binding resources are the LDS pipe and serial-recursion latency, see DESIGN.md section 5",
+            "traffic": pmc_traffic_bytes_per_launch() if (B == 4096 and N == 40) else None,
+            "note": "compute roof for f64: the dense fp64 MFMA peak and the fp64 vector-FMA peak are the same "
+                    "78.6 TFLOP/s on MI355X; this kernel's flops are vector FMAs (per-instance matrices are 6x6..9x9, "
+                    "no MFMA-shaped work).  Measured binding resources are the LDS pipe and serial-recursion "
+                    "latency, see DESIGN.md section 5; the HBM view is in 'hbm'",
             "kernel_ms": kernel_ms, "flops_per_solve": flops_per_solve(N, n_ipm_cold),
             "hbm": {"bound": "hbm", "achieved": by / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": by / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,

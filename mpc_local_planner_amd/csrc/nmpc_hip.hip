@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -259,14 +260,15 @@ struct KernelArgs {
     double *traj, *ctrl, *cost;
     int *status, *iters, *sqp_iters;
     unsigned char *reset;
+    const int *order;   // launch slot -> instance (longest expected solve first), or null
 };
 
 template <int NW>
 __global__ void __launch_bounds__(64 * NW, 2) nmpc_solve_kernel(KernelArgs a)
 {
     extern __shared__ double lds[];
-    const int inst = (int)blockIdx.x;
-    if (inst >= a.B) return;
+    if ((int)blockIdx.x >= a.B) return;
+    const int inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     nmpcw::InstanceIO io;
     io.x0 = a.x0 + (size_t)inst * 6;
     io.p = a.p + (size_t)inst * 6;
@@ -330,6 +332,42 @@ __global__ void nmpc_plant_kernel(double *ws, const double *pv, const double *ct
     for (int m = 0; m < 6; ++m) ws[(size_t)i * 6 + m] = w[m];
 }
 
+// Launch order for the next solve: instances sorted by the interior-point iterations of their
+// previous solve, longest first (counting sort, one workgroup).  Workgroups are dispatched in
+// blockIdx order and a CU holds 8 of them at a time, so a 4096-instance launch runs in two
+// rounds per CU and ends with a ragged tail (instances take 8..17 iterations); starting the long
+// ones first shortens it.  Iteration counts of consecutive calls are strongly correlated in closed
+// loop (warm start, no shift); with no history (all zero) the order is the identity.  The order
+// within one iteration count comes from atomics and may vary -- results do not depend on it.
+constexpr int ORDER_BINS = 256;
+__global__ void __launch_bounds__(1024) nmpc_order_kernel(const int *iters, int B, int *order)
+{
+    __shared__ int bin[ORDER_BINS];
+    __shared__ int any;
+    if (threadIdx.x < ORDER_BINS) bin[threadIdx.x] = 0;
+    if (threadIdx.x == 0) any = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        const int it = iters[i];
+        if (it != 0) any = 1;
+        atomicAdd(&bin[it < 0 ? 0 : (it >= ORDER_BINS ? ORDER_BINS - 1 : it)], 1);
+    }
+    __syncthreads();
+    if (!any) {     // no history: identity (uniform branch)
+        for (int i = threadIdx.x; i < B; i += blockDim.x) order[i] = i;
+        return;
+    }
+    if (threadIdx.x == 0) {     // start offsets, highest iteration count first
+        int run = 0;
+        for (int b = ORDER_BINS - 1; b >= 0; --b) { const int c = bin[b]; bin[b] = run; run += c; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        const int it = iters[i];
+        order[atomicAdd(&bin[it < 0 ? 0 : (it >= ORDER_BINS ? ORDER_BINS - 1 : it)], 1)] = i;
+    }
+}
+
 __global__ void nmpc_fill_rows_kernel(double *dst, int rows, int width, const double *vals8)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -366,8 +404,9 @@ struct nmpc_handle {
     int device;
     hipStream_t stream;
     double *d_x0, *d_p, *d_W, *d_bnd, *d_traj, *d_ctrl, *d_cost, *d_tmp;
-    int *d_status, *d_iters, *d_sqp;
+    int *d_status, *d_iters, *d_sqp, *d_order;
     unsigned char *d_reset, *d_mask;
+    bool ordered;                 // launch longest-expected instances first (NMPC_SCHEDULE=0 turns it off)
     const double *in_x0, *in_p;   // what the kernel reads (own buffers or caller's device buffers)
     std::vector<double> h_traj;
     // path front-end / closed loop (allocated by nmpc_set_track)
@@ -539,8 +578,10 @@ int nmpc_create(const nmpc_config *cfg, int capacity, int device, nmpc_handle **
         {(void **)&h->d_cost, cap * sizeof(double)},     {(void **)&h->d_tmp, 16 * sizeof(double)},
         {(void **)&h->d_status, cap * sizeof(int)},      {(void **)&h->d_iters, cap * sizeof(int)},
         {(void **)&h->d_sqp, cap * sizeof(int)},         {(void **)&h->d_reset, cap},
-        {(void **)&h->d_mask, cap},
+        {(void **)&h->d_mask, cap},                      {(void **)&h->d_order, cap * sizeof(int)},
     };
+    const char *sched = getenv("NMPC_SCHEDULE");
+    h->ordered = !(sched && sched[0] == '0');
     for (auto &a : allocs) *a.p = nullptr;
     bool ok = hip_ok(hipStreamCreate(&h->stream), "hipStreamCreate");
     for (auto &a : allocs) {
@@ -577,7 +618,7 @@ int nmpc_destroy(nmpc_handle *h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_x0, h->d_p, h->d_W, h->d_bnd, h->d_traj, h->d_ctrl, h->d_cost, h->d_tmp,
-                    h->d_status, h->d_iters, h->d_sqp, h->d_reset, h->d_mask,
+                    h->d_status, h->d_iters, h->d_sqp, h->d_order, h->d_reset, h->d_mask,
                     h->d_track, h->d_ws, h->d_pv, h->d_rot, h->d_xy};
     int rc = NMPC_OK;
     for (void *p : ptrs)
@@ -689,6 +730,13 @@ int nmpc_solve(nmpc_handle *h, int B, int mode, int max_iter, double tol)
     a.traj = h->d_traj; a.ctrl = h->d_ctrl; a.cost = h->d_cost;
     a.status = h->d_status; a.iters = h->d_iters; a.sqp_iters = h->d_sqp;
     a.reset = h->d_reset;
+    a.order = nullptr;
+    // (beyond ~8 rounds per CU the tail is a small part of the launch and the single-workgroup sort is not free)
+    if (h->ordered && B > 1 && B <= 16384) {
+        hipLaunchKernelGGL(nmpc_order_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_iters, B, h->d_order);
+        HIP_TRY(hipGetLastError());
+        a.order = h->d_order;
+    }
     const size_t lds_bytes = (size_t)nmpcw::lds_doubles(h->cfg.N) * sizeof(double);
     // one workgroup per instance: one wave (lane = shooting node) up to N = 63, two waves beyond
     if (nmpcw::waves_per_instance(h->cfg.N) == 1)

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Per-launch means of rocprofv3 PMC counters for one kernel.
+
+    python tools/pmc_summarize.py <dir with *_counter_collection.csv (searched recursively)> \
+        [kernel substring = nmpc_solve_kernel] [instances per launch = 4096] > profiles/<round>/pmc_summary.json
+
+Each `--pmc` pass is its own run (rocprofv3 does not split counters over passes); point this at
+the directory that holds all of them.  Values are summed over the dimensions rocprofv3 lists per
+dispatch (XCC / SE / instance rows) and averaged over the launches of the kernel.
+"""
+import csv
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def main():
+    root = sys.argv[1]
+    kern = sys.argv[2] if len(sys.argv) > 2 else "nmpc_solve_kernel"
+    per_launch = float(sys.argv[3]) if len(sys.argv) > 3 else 4096.0
+    out = {}
+    meta = None
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if not f.endswith("counter_collection.csv"):
+                continue
+            vals = defaultdict(lambda: defaultdict(float))   # counter -> dispatch -> sum
+            with open(os.path.join(dp, f), newline="") as fh:
+                for row in csv.DictReader(fh):
+                    if kern not in row["Kernel_Name"]:
+                        continue
+                    if meta is None:
+                        meta = {k: row[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size",
+                                                    "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count") if k in row}
+                    vals[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+            for name, d in vals.items():
+                m = sum(d.values()) / len(d)
+                out[name] = {"launches": len(d), "mean_per_launch": m, "per_solve": m / per_launch}
+    json.dump({"_kernel_meta": meta, **out}, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()

@@ -108,7 +108,10 @@ int nmpc_set_iterate(nmpc_handle *h, const double *x, const double *u, int B);
 
 /* Replaces path_tracking_acados_solve (src/AcadosPathTracking.cpp:26) for instances 0..B-1:
  * NMPC_MODE_RTI = one SQP-RTI iteration (rti_phase 0, src/AcadosSolver.cpp:42-48);
- * NMPC_MODE_SQP = up to max_iter iterations until the step is below tol.
+ * NMPC_MODE_SQP = up to max_iter iterations, stopping as acados' ocp_nlp_sqp does: when the NLP's KKT
+ *   residuals at the current iterate with the last QP's multipliers (stationarity, shooting gaps, bound
+ *   violation, complementarity; infinity norms) are all <= tol (acados default 1e-6); status 2 after
+ *   max_iter QPs otherwise.
  * Asynchronous on the handle's stream; iterates stay on the device (warm start, no shift,
  * src/PathTrackingSys.cpp:58-61). */
 int nmpc_solve(nmpc_handle *h, int B, int mode, int max_iter, double tol);

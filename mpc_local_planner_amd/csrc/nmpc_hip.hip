@@ -22,8 +22,10 @@ namespace {
 
 // NW = waves per OCP instance (= per workgroup): 1 for N <= 63, 2 for N <= 127.  The sweeps always
 // run on the first wave; the other wave only takes part in the stage-layout work.
-template <int NW>
+// SQP = full SQP mode (the RTI instantiation carries none of the KKT-residual / costate code).
+template <int NW, bool SQP>
 struct GpuWave {
+    static constexpr bool kSqp = SQP;
     double *lds_;
     double *pol_;      // NW > 1: [2][4] reduction slots, then [128] exchange slots
     int flip_ = 0;
@@ -263,7 +265,7 @@ struct KernelArgs {
     const int *order;   // launch slot -> instance (longest expected solve first), or null
 };
 
-template <int NW>
+template <int NW, bool SQP>
 __global__ void __launch_bounds__(64 * NW, 2) nmpc_solve_kernel(KernelArgs a)
 {
     extern __shared__ double lds[];
@@ -281,7 +283,7 @@ __global__ void __launch_bounds__(64 * NW, 2) nmpc_solve_kernel(KernelArgs a)
     io.sqp_iters = a.sqp_iters + inst;
     io.cost = a.cost + inst;
     io.cold = a.reset[inst];
-    GpuWave<NW> w{lds, lds + (a.pb.N + 1) * nmpcw::ST + nmpcw::X_SIZE};
+    GpuWave<NW, SQP> w{lds, lds + (a.pb.N + 1) * nmpcw::ST + nmpcw::X_SIZE};
     nmpcw::solve_instance(w, a.pb, io);
     // failed instances restart cold next time (reference: reInit on status != 0,
     // src/AcadosSolver.cpp:56-59); successful ones keep their iterate (warm start)
@@ -594,10 +596,13 @@ int nmpc_create(const nmpc_config *cfg, int capacity, int device, nmpc_handle **
     if (ok) {
         const int lds_bytes = nmpcw::lds_doubles(cfg->N) * (int)sizeof(double);
         if (lds_bytes > 48 * 1024) {
-            const void *fn = nmpcw::waves_per_instance(cfg->N) == 1 ? (const void *)nmpc_solve_kernel<1>
-                                                                    : (const void *)nmpc_solve_kernel<2>;
-            ok = hip_ok(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes),
-                        "hipFuncSetAttribute");
+            const bool one = nmpcw::waves_per_instance(cfg->N) == 1;
+            const void *fns[2] = {one ? (const void *)nmpc_solve_kernel<1, false> : (const void *)nmpc_solve_kernel<2, false>,
+                                  one ? (const void *)nmpc_solve_kernel<1, true> : (const void *)nmpc_solve_kernel<2, true>};
+            for (const void *fn : fns)
+                if (ok)
+                    ok = hip_ok(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes),
+                                "hipFuncSetAttribute");
         }
     }
     if (!ok) {
@@ -739,10 +744,14 @@ int nmpc_solve(nmpc_handle *h, int B, int mode, int max_iter, double tol)
     }
     const size_t lds_bytes = (size_t)nmpcw::lds_doubles(h->cfg.N) * sizeof(double);
     // one workgroup per instance: one wave (lane = shooting node) up to N = 63, two waves beyond
-    if (nmpcw::waves_per_instance(h->cfg.N) == 1)
-        hipLaunchKernelGGL(nmpc_solve_kernel<1>, dim3(B), dim3(64), lds_bytes, h->stream, a);
-    else
-        hipLaunchKernelGGL(nmpc_solve_kernel<2>, dim3(B), dim3(128), lds_bytes, h->stream, a);
+    const bool one = nmpcw::waves_per_instance(h->cfg.N) == 1;
+    if (mode == NMPC_MODE_RTI) {
+        if (one) hipLaunchKernelGGL((nmpc_solve_kernel<1, false>), dim3(B), dim3(64), lds_bytes, h->stream, a);
+        else hipLaunchKernelGGL((nmpc_solve_kernel<2, false>), dim3(B), dim3(128), lds_bytes, h->stream, a);
+    } else {
+        if (one) hipLaunchKernelGGL((nmpc_solve_kernel<1, true>), dim3(B), dim3(64), lds_bytes, h->stream, a);
+        else hipLaunchKernelGGL((nmpc_solve_kernel<2, true>), dim3(B), dim3(128), lds_bytes, h->stream, a);
+    }
     HIP_TRY(hipGetLastError());
     return NMPC_OK;
 }

@@ -246,9 +246,14 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
     bool tables_ready = false;
     double a33 = 0.0, a35 = 0.0, b31 = 0.0;   // constant entries of [B A] (row v)
 
-    for (sqp_it = 0; sqp_it < pb.sqp_max_iter; ++sqp_it) {
+    // SQP mode (W::kSqp, a compile-time property of the policy): multipliers of the last QP, for
+    // the KKT residuals at the next iterate -- costate pi_k of this node, bound multipliers
+    double pik[6] = {0, 0, 0, 0, 0, 0}, lam_l[4] = {0, 0, 0, 0}, lam_u[4] = {0, 0, 0, 0};
+
+    for (sqp_it = 0;; ++sqp_it) {
         // ------------------------------------------------------------ linearise (stage layout)
         double rb[6], g[8], Q00, Q01, Q02;
+        double kkt = 0.0;   // SQP mode: largest KKT residual of this node
         {
             double gp, gpc;
             sincos_bounded(io.p[4], &gp, &gpc);
@@ -259,6 +264,22 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
             for (int m = 0; m < 6; ++m) {
                 const double xn = w.shfl_down1(xb[m]);       // x_{k+1} from the next lane
                 rb[m] = act ? (phi[m] - xn) : 0.0;
+                if (W::kSqp) kkt = fmax(kkt, fabs(rb[m]));                      // res_eq: shooting gaps
+                if (W::kSqp && tid == 0) kkt = fmax(kkt, fabs(io.x0[m] - xb[m]));   //         and x_0 = x0
+            }
+            double Atp[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // SQP mode: [B A]' pi_{k+1} in z ordering
+            if (W::kSqp) {
+                double pn[6];
+#pragma unroll
+                for (int m = 0; m < 6; ++m) pn[m] = w.shfl_down1(pik[m]);
+                Atp[0] = aX[4] * pn[0] + aY[4] * pn[1] + aP[4] * pn[2] + h * pn[4];
+                Atp[1] = aX[5] * pn[0] + aY[5] * pn[1] + aP[5] * pn[2] + aV[5] * pn[3] + h * pn[5];
+                Atp[2] = pn[0];
+                Atp[3] = pn[1];
+                Atp[4] = aX[0] * pn[0] + aY[0] * pn[1] + aP[0] * pn[2];
+                Atp[5] = aX[1] * pn[0] + aY[1] * pn[1] + aP[1] * pn[2] + aV[1] * pn[3];
+                Atp[6] = aX[2] * pn[0] + aY[2] * pn[1] + aP[2] * pn[2] + pn[4];
+                Atp[7] = aX[3] * pn[0] + aY[3] * pn[1] + aP[3] * pn[2] + aV[3] * pn[3] + pn[5];
             }
             if (tid == 0) {   // fold the known dx_0 = x0 - x_0 into the first gap: b_0 += A_0 dx0
                 double d[6];
@@ -330,6 +351,31 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                                       Q44 * xb[4] * xb[4] + Q55 * xb[5] * xb[5] +
                                       R00 * ub_[0] * ub_[0] + R11 * ub_[1] * ub_[1]);
             cost_out = w.sum(act ? cst : 0.0);
+            if (W::kSqp) {
+                // NLP KKT residuals at this iterate with the last QP's multipliers: acados' SQP
+                // termination test (stationarity, equality, inequality, complementarity, each in the
+                // infinity norm against one tolerance); stage N has neither cost nor bounds
+                if (act) {
+                    kkt = fmax(kkt, fabs(g[0] + Atp[0] - lam_l[0] + lam_u[0]));
+                    kkt = fmax(kkt, fabs(g[1] + Atp[1] - lam_l[1] + lam_u[1]));
+                }
+                if (actx) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) kkt = fmax(kkt, fabs(g[2 + m] + Atp[2 + m] - pik[m]));
+                    kkt = fmax(kkt, fabs(g[6] + Atp[6] - pik[4] - lam_l[2] + lam_u[2]));
+                    kkt = fmax(kkt, fabs(g[7] + Atp[7] - pik[5] - lam_l[3] + lam_u[3]));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double v = q == 0 ? ub_[0] : q == 1 ? ub_[1] : q == 2 ? xb[4] : xb[5];
+                    const bool on = q < 2 ? act : actx;
+                    const double sl = v - lb[q], su = ub[q] - v;
+                    if (on) kkt = fmax(kkt, fmax(fmax(-sl, -su), fmax(fabs(lam_l[q] * sl), fabs(lam_u[q] * su))));
+                }
+                const double res = w.max(kkt);
+                if (sqp_it > 0 && res <= pb.sqp_tol) { status = 0; break; }
+                if (sqp_it >= pb.sqp_max_iter) { status = 2; break; }
+            }
         }
 
         // ------------------------------------------------------------ interior point (stage layout)
@@ -738,15 +784,45 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
             for (int m = 0; m < 6; ++m) xb[m] = io.x0[m];
         }
         status = qp_status;
-        if (qp_status != 0) { ++sqp_it; break; }
-        if (pb.sqp_max_iter > 1) {
-            double sl = 0.0;
+        if (qp_status != 0 || !W::kSqp) { ++sqp_it; break; }
+        // ---- SQP mode: multipliers of this QP for the next KKT test.  Costates by the adjoint
+        // recursion of the QP's x-stationarity: pi_N = 0, pi_k = H_xx dx_k + q_k + A_k' pi_{k+1}
+        // (+ bound multipliers on delta, thr), k = N-1 .. 1 -- one more serial sweep, with the
+        // stage data of THIS linearisation still in LDS
 #pragma unroll
-            for (int m = 0; m < 8; ++m) sl = fmax(sl, fabs(z[m]));
-            const double step = w.max(has_node ? sl : 0.0);
-            if (step <= pb.sqp_tol) { ++sqp_it; status = 0; break; }
-            if (sqp_it + 1 >= pb.sqp_max_iter) status = 2;
+        for (int q = 0; q < 4; ++q) { lam_l[q] = ll[q]; lam_u[q] = lu[q]; }
+        if (act) {
+            double *sl = stg + tid * ST + O_D;
+            st2(sl + 0, Q00 * z[2] + Q01 * z[3] + Q02 * z[4] + g[2], Q01 * z[2] + Q11 * z[3] + g[3]);
+            st2(sl + 2, Q02 * z[2] + Q22 * z[4] + g[4], Q33 * z[5] + g[5]);
+            st2(sl + 4, Q44 * z[6] + g[6] - ll[2] + lu[2], Q55 * z[7] + g[7] - ll[3] + lu[3]);
         }
+        w.sync();
+        if (w.sweep_wave()) {
+            const int c = lane < 6 ? lane : 5;      // lanes 0..5 own component c of the costate
+            const double a3 = c == 3 ? a33 : c == 5 ? a35 : 0.0;           // A[v][c]
+            const double a4 = c == 4 ? 1.0 : 0.0, a5 = c == 5 ? 1.0 : 0.0;  // A[delta][c], A[thr][c]
+            double pi = 0.0;
+#pragma unroll 1
+            for (int k = N - 1; k >= 1; --k) {
+                double *sk = stg + k * ST;
+                const double *col = sk + GS * c + G_XY;     // rows X,Y,psi of column c (c >= 2)
+                const double a0 = c == 0 ? 1.0 : c == 1 ? 0.0 : col[0];
+                const double a1 = c == 0 ? 0.0 : c == 1 ? 1.0 : col[1];
+                const double a2 = c < 2 ? 0.0 : col[2];
+                const double p0 = w.readlane(pi, 0), p1 = w.readlane(pi, 1), p2 = w.readlane(pi, 2),
+                             p3 = w.readlane(pi, 3), p4 = w.readlane(pi, 4), p5 = w.readlane(pi, 5);
+                pi = sk[O_D + c] + a0 * p0 + a1 * p1 + a2 * p2 + a3 * p3 + a4 * p4 + a5 * p5;
+                if (lane < 6) sk[O_D + c] = pi;
+            }
+        }
+        w.sync();
+        {
+            const double *src = stg + node * ST + O_D;
+#pragma unroll
+            for (int m = 0; m < 6; ++m) pik[m] = actx ? src[m] : 0.0;
+        }
+        w.sync();
     }
 
     // ---------------------------------------------------------------- write back

@@ -37,6 +37,7 @@ struct Sched {
     Barrier wg, wave[MAXT / WAVE];
     long spins = 0;
     bool deadlock = false;
+    bool sqp = false;           // SQP mode (the host picks the instantiation by mode, as nmpc_solve does)
     const nmpcw::Problem *pb = nullptr;
     const nmpcw::InstanceIO *io = nullptr;
 };
@@ -75,7 +76,9 @@ void barrier(Barrier &b, int nthreads, int t)
     } while (b.gen == gen);
 }
 
+template <bool SQP>
 struct EmuWave {
+    static constexpr bool kSqp = SQP;   // same two instantiations as the GPU policy
     int tid_;
     int tid() const { return tid_; }
     int lane() const { return tid_ & (WAVE - 1); }
@@ -185,8 +188,13 @@ struct EmuWave {
 
 void thread_main(int t)
 {
-    EmuWave w{t};
-    nmpcw::solve_instance(w, *g_s->pb, *g_s->io);
+    if (g_s->sqp) {
+        EmuWave<true> w{t};
+        nmpcw::solve_instance(w, *g_s->pb, *g_s->io);
+    } else {
+        EmuWave<false> w{t};
+        nmpcw::solve_instance(w, *g_s->pb, *g_s->io);
+    }
     g_s->done[t] = true;
     for (int i = 1; i < g_s->nt; ++i) {
         const int n = (t + i) % g_s->nt;
@@ -204,14 +212,16 @@ extern "C" int emu_solve_batch(int N, double dt, double wheelbase, int ipm_max_i
                                double *ctrl, int *status, int *iters, int *sqp_iters, double *cost,
                                int cold)
 {
+    // sqp_max_iter <= 0: one SQP-RTI iteration; > 0: SQP mode with that many iterations at most
     if (N < 1 || N > 127) return 2;
     nmpcw::Problem pb;
     pb.N = N; pb.dt = dt; pb.inv_wheelbase = 1.0 / wheelbase;
     pb.ipm_max_iter = ipm_max_iter; pb.mu0 = mu0; pb.thr0 = thr0; pb.tau = tau;
     pb.tol_mu = tol_mu; pb.tol_lin = tol_lin; pb.tol_comp = tol_comp;
-    pb.sqp_max_iter = sqp_max_iter; pb.sqp_tol = sqp_tol;
+    pb.sqp_max_iter = sqp_max_iter > 0 ? sqp_max_iter : 1; pb.sqp_tol = sqp_tol;
     Sched s;
     g_s = &s;
+    s.sqp = sqp_max_iter > 0;
     s.nt = WAVE * nmpcw::waves_per_instance(N);
     s.stacks.resize(STACK * s.nt);
     std::vector<double> lds((size_t)nmpcw::lds_doubles(N) + 2);

@@ -49,8 +49,10 @@ def plant_step(ws, delta_cmd, thr_cmd, pitch, dtp, wheelbase=2.65, steering_rati
     return ws
 
 
-def solve_batch(cfg, x0, p, W=None, bnd=None, traj=None, cold=True, sqp_max_iter=1, sqp_tol=1e-6):
-    """cfg: any config struct with the nmpc_config field names.  Returns dict like BatchSolver.get."""
+def solve_batch(cfg, x0, p, W=None, bnd=None, traj=None, cold=True, sqp_max_iter=0, sqp_tol=1e-6):
+    """cfg: any config struct with the nmpc_config field names.  sqp_max_iter = 0: one SQP-RTI
+    iteration; > 0: SQP mode, at most that many iterations (KKT residuals <= sqp_tol).  Returns a
+    dict like BatchSolver.get."""
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     p = np.ascontiguousarray(p, dtype=np.float64)
     B, N = x0.shape[0], cfg.N

@@ -171,8 +171,9 @@ def test_per_instance_weights_and_bounds():
 
 def test_config4_full_sqp_with_active_bounds():
     """BASELINE config 4: full SQP (up to 20 iterations), N = 100, steering/throttle bounds active.
-    The kernel stops on the step norm, the oracle on the KKT residuals: both are run to a tight
-    tolerance and must agree on the fixed point."""
+    Kernel and oracle stop on the same test (acados': the NLP's KKT residuals -- stationarity,
+    shooting gaps, bound violation, complementarity -- with the last QP's multipliers, all <= tol),
+    so they must take the same number of SQP iterations and agree on the iterate."""
     N, B = 100, 32
     x0, p = sc.config4(B)
     s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
@@ -182,14 +183,17 @@ def test_config4_full_sqp_with_active_bounds():
     g = s.get(B)
     ocfg = _ocfg(N)
     c = capi.default_config(N, 0.35)
-    n_ok = n_active = 0
+    n_ok = n_active = n_same = 0
     for i in range(B):
         xo, uo = orc.init_guess(ocfg, x0[i])
         st = orc.sqp(ocfg, x0[i], p[i], xo, uo, 20, 1e-8)
         if st.status != 0 or g["status"][i] != 0:
+            # non-convergent full-step iterations amplify round-off: only the kind of failure is compared
             assert st.status == g["status"][i] or {st.status, int(g["status"][i])} <= {0, 2}
             continue
         n_ok += 1
+        n_same += int(g["sqp_iters"][i] == st.sqp_iters)
+        assert abs(int(g["sqp_iters"][i]) - st.sqp_iters) <= 1     # (a residual within round-off of tol)
         sc_ = _scale(xo, uo)
         assert np.abs(g["x"][i] - xo).max() <= 1e-6 * sc_, (i, np.abs(g["x"][i] - xo).max())
         assert np.abs(g["u"][i] - uo).max() <= 1e-6 * sc_, (i, np.abs(g["u"][i] - uo).max())
@@ -201,6 +205,40 @@ def test_config4_full_sqp_with_active_bounds():
     # full-step SQP (no globalisation, as acados' default) does not converge from every one of
     # these hard starts within 20 iterations -- on either side; those that do must agree
     assert n_ok >= B // 4 and n_active >= n_ok // 2      # and the case does exercise active bounds
+    assert n_same >= n_ok - 1
+    s.close()
+
+
+def test_sqp_mode_config2_same_iterations_as_oracle():
+    """SQP mode on the config-2 distribution (N = 40): the instances whose full-step iteration
+    converges (about three in four; no globalisation, as acados' default) take exactly the
+    oracle's number of SQP iterations to the oracle's iterate, the others end with status 2 on
+    both sides; max_iter = 2 with an unreachable tolerance gives status 2 after exactly two QPs."""
+    N, B = 40, 48
+    x0, p = sc.config2(B)
+    s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
+    s.set_x0(x0)
+    s.set_params(p)
+    s.solve(B, mode=capi.MODE_SQP, max_iter=30, tol=1e-8)
+    g = s.get(B)
+    ocfg = _ocfg(N)
+    n_ok = 0
+    for i in range(B):
+        xo, uo = orc.init_guess(ocfg, x0[i])
+        st = orc.sqp(ocfg, x0[i], p[i], xo, uo, 30, 1e-8)
+        assert st.status == g["status"][i] and st.status in (0, 2)
+        assert g["sqp_iters"][i] == st.sqp_iters
+        if st.status != 0:
+            continue
+        n_ok += 1
+        sc_ = _scale(xo, uo)
+        assert np.abs(g["x"][i] - xo).max() <= 1e-7 * sc_ and np.abs(g["u"][i] - uo).max() <= 1e-7 * sc_
+        assert abs(g["cost"][i] - st.cost) <= 1e-9 * max(1.0, abs(st.cost))
+    assert n_ok >= B // 2
+    s.reset(None, B)
+    s.solve(B, mode=capi.MODE_SQP, max_iter=2, tol=1e-13)
+    g = s.get(B)
+    assert (g["status"] == 2).all() and (g["sqp_iters"] == 2).all()
     s.close()
 
 

@@ -87,6 +87,9 @@ struct GpuWave {
             : "v"(lds_addr(p1)), "v"(lds_addr(p3)), "v"(lds_addr(p2))
             : "memory");
     }
+    // EXEC-masking the lanes with constant operands out of the per-stage loads was tried (it removes
+    // their bank conflicts with the stage data: SQ_LDS_BANK_CONFLICT 15.1k -> 8.2k per solve) and lost
+    // 3 % overall: each s_mov exec ahead of a vector instruction costs more than the conflict cycles.
     __device__ __forceinline__ void fwd_stage(double (&cur)[9], double (&nxt)[9], const double *p1,
                                               const double *p3, const double *p2, double *sw, double &val)
     {
@@ -121,7 +124,8 @@ struct GpuWave {
             : [c0] "v"(cur[0]), [c1] "v"(cur[1]), [c2] "v"(cur[2]), [c3] "v"(cur[3]), [c4] "v"(cur[4]),
               [c5] "v"(cur[5]), [e0] "v"(cur[6]), [e1] "v"(cur[7]), [a1] "v"(lds_addr(p1)), [a3] "v"(lds_addr(p3)),
               [a2] "v"(lds_addr(p2)), [sw] "v"(lds_addr(sw))
-            : "memory");        val = t;
+            : "memory");
+        val = t;
     }
     // d[0..2] = tv[0..2], d[3] = dg[0], d[4,5] = ab[0,1]
     __device__ __forceinline__ void bwd_fetch(const double *tv, const double *dg, const double *ab, double (&d)[6])

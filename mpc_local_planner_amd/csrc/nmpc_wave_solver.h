@@ -86,9 +86,16 @@ constexpr int ST = 54;          // per stage
 constexpr int GS = 6;           // group stride
 constexpr int G_K = 0;          //   gain pair of the column (psi..thr); zero in the groups u0,u1
 constexpr int G_XY = 2;         //   rows X,Y (pair), row psi at +2
-constexpr int O_E = 36;         // (K0[X],K1[X]), (K0[Y],K1[Y]), (kff0,kff1)
-constexpr int O_INV = 42;       // rows of -inv(Huu): (-i00,-i01), (-i01,-i11)
-constexpr int O_D = 46;         // slot k: rb_k as [0,1,2,-,3,4,5,-] -> z_{k+1}[8] = du,dx -> dG_k[4]
+constexpr int O_E = 36;         // (K0[X],K1[X]), (K0[Y],K1[Y])
+constexpr int O_KFF = 40;       // (kff0,kff1)
+constexpr int O_INV0 = 42;      // rows of -inv(Huu): (-i00,-i01) here, (-i01,-i11) at O_INV1
+constexpr int O_D = 44;         // slot k: rb_k as [0,1,2,-,3,4,5,-] -> z_{k+1}[8] = du,dx -> dG_k[4]
+constexpr int O_INV1 = 52;
+// The order of these tail blocks is chosen so that every per-stage read of the sweeps is free of
+// LDS bank conflicts (tools/lds_conflicts.py): the gain pairs, the rows of -inv(Huu) and the start
+// of O_D fall on different banks than the column groups they are read together with.  What is left
+// are the lanes whose operand is a constant from a table outside the stage (unit columns, constant
+// rows): they collide with the stage data at some stage alignments.
 // input view of the factor sweep, overlaying the gain/inverse slots it writes afterwards
 constexpr int I_GAM01 = 12, I_GAM23 = 18, I_Q0 = 24, I_Q2 = 30;   // (gam0,gam1) (gam2,gam3) (Q00,Q01) (Q02,-)
 constexpr int I_G = 36;         // G[8]
@@ -102,7 +109,10 @@ constexpr int X_DUM = 138;      // dummy target for lanes with nothing to store
 constexpr int X_UNIT = 142;     // (1,0,0,-),(0,1,0,-): rows X,Y,psi of columns X,Y
 constexpr int X_ZERO = 150;     // 0,0,0,0
 constexpr int X_FT = 154;       // 1,0,0,0,1,0: forward-sweep coefficients of dx_X, dx_Y for the state rows
-constexpr int X_SIZE = 160;
+constexpr int X_UNITB = 161;    // (1,0,0),-,(0,1,0): the unit columns again at ODD addresses for the backward sweep's
+                                // 8-byte loads: the stage lanes read even, odd, even addresses there, the unit lanes
+                                // odd, even, odd -- different banks at every stage alignment
+constexpr int X_SIZE = 168;
 // horizons beyond 63 use two waves per instance (lane = node needs 128 threads); their cross-wave
 // reductions and the x_{k+1} hand-over go through a small extra area owned by the wave policy
 constexpr int X_POLICY = 8 + 128;
@@ -206,7 +216,7 @@ NMPC_DEV void rk4_sens(const Problem &pb, const double *x, const double *u, doub
 // variable-column index of z index j (u0,u1,-,-,psi,v,delta,thr) -> 0,1,-,-,2,3,4,5
 #define NMPC_VCOL(j) ((j) < 2 ? (j) : (j) - 2)
 // stage offset of the gain pair (K0[c],K1[c]), c = X,Y,psi,v,delta,thr; c = 6: (kff0,kff1)
-#define NMPC_KOFF(c) ((c) < 2 ? O_E + 2 * (c) : (c) < 6 ? GS * (c) + G_K : O_E + 4)
+#define NMPC_KOFF(c) ((c) < 2 ? O_E + 2 * (c) : (c) < 6 ? GS * (c) + G_K : O_KFF)
 
 template <class W>
 NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
@@ -317,6 +327,8 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     c[5 * GS] = a35; c[5 * GS + 1] = 0.0; c[5 * GS + 2] = 1.0;     // thr
                     double *u = xa + X_UNIT;
                     u[0] = 1.0; u[1] = 0.0; u[2] = 0.0; u[3] = 0.0; u[4] = 0.0; u[5] = 1.0; u[6] = 0.0; u[7] = 0.0;
+                    double *ub2 = xa + X_UNITB;
+                    ub2[0] = 1.0; ub2[1] = 0.0; ub2[2] = 0.0; ub2[3] = 0.0; ub2[4] = 0.0; ub2[5] = 1.0; ub2[6] = 0.0;
                     double *zz = xa + X_ZERO;
                     zz[0] = 0.0; zz[1] = 0.0; zz[2] = 0.0; zz[3] = 0.0;
                     double *ft = xa + X_FT;
@@ -518,7 +530,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     if (f2j <= 7) pPw2 = xa + X_P + (f2j - 2) * 8 + (f2i - 2);
                     if (f2i == 2) { kw = last + NMPC_KOFF(f2j - 2); sKw = ST; }
                 }
-                if (fl == 44 || fl == 45) { kw = last + O_INV + 2 * (fl - 44); sKw = ST; }
+                if (fl == 44 || fl == 45) { kw = last + (fl == 44 ? O_INV0 : O_INV1); sKw = ST; }
                 // rows v,delta,thr of column i are constants: loaded once per sweep
                 const D2 v01 = ld2(pBotI);
                 const double v2 = pBotI[2];
@@ -586,17 +598,19 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     const int vl = bl & 7;
                     const double *tv;                 // column vl of [B A], rows X,Y,psi
                     int sTopV;
-                    if (vl == 2 || vl == 3) { tv = xa + X_UNIT + 4 * (vl - 2); sTopV = 0; }
+                    if (vl == 2 || vl == 3) { tv = xa + X_UNITB + 4 * (vl - 2); sTopV = 0; }
                     else { tv = last + GS * NMPC_VCOL(vl) + G_XY; sTopV = ST; }
-                    const double *dg = xa + X_ZERO;   // corrector gradient entry of component vl
-                    int sDgV = 0;
-                    if (vl < 2) { dg = last + O_D + vl; sDgV = ST; }
-                    if (vl >= 6) { dg = last + O_D + vl - 4; sDgV = ST; }
+                    // corrector gradient entry of component vl; zero for the other components, read from
+                    // the zero the stage keeps next to it (this operand is also the accumulator of the
+                    // stage's multiply-add chain, so it is loaded afresh every stage by all lanes -- from
+                    // inside the stage, hence without bank conflicts)
+                    const double *dg = last + O_D + (vl < 2 ? vl : vl >= 6 ? vl - 4 : 4);
+                    const int sDgV = ST;
                     // res = keep * hc + ab.x * hc[0] + ab.y * hc[1]: lanes >= 2 form p_new with their gain
                     // pair (K0,K1); lanes 0,1 form kff = -(inv hu) with row vl of -inv
-                    const double *ab = vl >= 2 ? last + NMPC_KOFF(vl - 2) : last + O_INV + 2 * vl;
+                    const double *ab = vl >= 2 ? last + NMPC_KOFF(vl - 2) : last + (vl == 0 ? O_INV0 : O_INV1);
                     const double keep = vl >= 2 ? 1.0 : 0.0;
-                    double *kfw = bl < 2 ? last + O_E + 4 + bl : xa + X_DUM;
+                    double *kfw = bl < 2 ? last + O_KFF + bl : xa + X_DUM;
                     const int sKfw = bl < 2 ? ST : 0;
                     // rows v,delta,thr of column vl
                     const double cb0 = vl == 1 ? b31 : vl == 5 ? a33 : vl == 7 ? a35 : 0.0;
@@ -643,9 +657,9 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     // start value: r_b (affine pass only) or kff
                     const double *p2;
                     int s2;
-                    if (vl >= 6) { p2 = stg + O_E + 4 + (vl - 6); s2 = ST; }
+                    if (vl >= 6) { p2 = stg + O_KFF + (vl - 6); s2 = ST; }
                     else if (pass == 0) { p2 = stg + O_D + (vl < 3 ? vl : vl + 1); s2 = ST; }
-                    else { p2 = xa + X_ZERO; s2 = 0; }
+                    else { p2 = stg + O_D + 4; s2 = ST; }     // the zero next to the corrector rhs (see E-B)
                     double *sw = xa + X_DUM;          // dx_{k+1}[r] -> slot k, du_k[a] -> slot k-1
                     int sSw = 0;
                     if (fl < 6) { sw = stg + O_D + 2 + fl; sSw = ST; }
@@ -726,6 +740,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                             dG[q] = mq[q] ? (-ctl * itl[q] + ctu * itu[q]) : 0.0;
                         }
                         st2(sl, dG[0], dG[1]); st2(sl + 2, dG[2], dG[3]);
+                        st2(sl + 4, 0.0, 0.0);     // the zero operand of the second pass (read next to dG)
                     }
                     w.sync();
                 } else {

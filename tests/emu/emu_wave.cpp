@@ -98,7 +98,9 @@ struct EmuWave {
                    double *sw, double &val)
     {
         fwd_fetch(p1, p3, p2, nxt);
-        double vA = fmac_row<0>(cur[8], val, cur[6]);
+        const double start = cur[8];
+        cur[8] = -1e300 * 1e10;     // the GPU policy accumulates into it: consumed
+        double vA = fmac_row<0>(start, val, cur[6]);
         double vB = fmac_row<1>(0.0, val, cur[7]);
         vA = fmac_row<2>(vA, val, cur[2]);
         vB = fmac_row<3>(vB, val, cur[3]);
@@ -120,7 +122,9 @@ struct EmuWave {
                    double *kfw, double cb0, double cb1, double cb2, double keep, double &res)
     {
         bwd_fetch(tv, dg, ab, nxt);
-        double hA = fmac_row<2>(cur[3], res, cur[0]);
+        const double g0 = cur[3];
+        cur[3] = -1e300 * 1e10;     // consumed, as on the GPU
+        double hA = fmac_row<2>(g0, res, cur[0]);
         double hB = fmac_row<3>(0.0, res, cur[1]);
         hA = fmac_row<4>(hA, res, cur[2]);
         hB = fmac_row<5>(hB, res, cb0);

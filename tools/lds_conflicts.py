@@ -12,9 +12,11 @@ layout constants below together with the header when trying a new layout.
 import sys
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-ST, GS, G_K, G_XY, O_E, O_INV, O_D = 54, 6, 0, 2, 36, 42, 46
+ST, GS, G_K, G_XY, O_E, O_KFF, O_INV0, O_D, O_INV1 = 54, 6, 0, 2, 36, 40, 42, 44, 52
+MASKED_SWEEPS = False        # vector sweeps: lanes with constant operands are EXEC-masked out of the per-stage loads
+MASKED_FACTOR = False        # factor sweep: not masked (compiler-generated loop)
 I_GAM01, I_GAM23, I_Q0, I_Q2, I_G = 12, 18, 24, 30, 36
-X_P, X_M, X_HU, X_DUM, X_UNIT, X_ZERO, X_FT = 0, 48, 116, 138, 142, 150, 154
+X_P, X_M, X_HU, X_DUM, X_UNIT, X_ZERO, X_FT, X_UNITB = 0, 48, 116, 138, 142, 150, 154, 161
 CT = 0                       # pseudo-stage -1 (doubles from the LDS base)
 STG = CT + ST
 XA = CT + (N + 1) * ST
@@ -51,7 +53,7 @@ def vcol(j):
 
 
 def koff(c):
-    return O_E + 2 * c if c < 2 else (GS * c + G_K if c < 6 else O_E + 4)
+    return O_E + 2 * c if c < 2 else (GS * c + G_K if c < 6 else O_KFF)
 
 
 def bwd(k):
@@ -60,11 +62,12 @@ def bwd(k):
     tv, dg, ab = [], [], []
     for lane in range(64):
         vl = lane & 7
-        tv.append(XA + X_UNIT + 4 * (vl - 2) if vl in (2, 3) else S + GS * vcol(vl) + G_XY)
-        dg.append(S + O_D + vl if vl < 2 else (S + O_D + vl - 4 if vl >= 6 else XA + X_ZERO))
-        ab.append(S + koff(vl - 2) if vl >= 2 else S + O_INV + 2 * vl)
+        const = None if MASKED_SWEEPS else 0
+        tv.append((XA + X_UNITB + 4 * (vl - 2) if const is not None else None) if vl in (2, 3) else S + GS * vcol(vl) + G_XY)
+        dg.append(S + O_D + (vl if vl < 2 else vl - 4 if vl >= 6 else 4))
+        ab.append(S + koff(vl - 2) if vl >= 2 else S + (O_INV0 if vl == 0 else O_INV1))
     for off in range(3):
-        tot += conflict_cycles([a + off for a in tv], 1)
+        tot += conflict_cycles([None if a is None else a + off for a in tv], 1)
     tot += conflict_cycles(dg, 1)
     for off in range(2):
         tot += conflict_cycles([a + off for a in ab], 1)
@@ -76,18 +79,20 @@ def fwd(k, pas):
     p1, p3, p2 = [], [], []
     for lane in range(64):
         vl = lane & 7
-        p1.append(S + G_XY + vl if vl < 3 else (CT + G_XY + (vl - 3) if vl < 6 else S + G_K + (vl - 6)))
-        p3.append(XA + X_FT + (0 if vl == 0 else 2 if vl == 1 else 1) if vl < 6 else S + O_E + (vl - 6))
+        m = MASKED_SWEEPS
+        p1.append(S + G_XY + vl if vl < 3 else ((None if m else CT + G_XY + (vl - 3)) if vl < 6 else S + G_K + (vl - 6)))
+        p3.append((None if m else XA + X_FT + (0 if vl == 0 else 2 if vl == 1 else 1)) if vl < 6 else S + O_E + (vl - 6))
         if vl >= 6:
-            p2.append(S + O_E + 4 + (vl - 6))
+            p2.append(S + O_KFF + (vl - 6))
         elif pas == 0:
             p2.append(S + O_D + (vl if vl < 3 else vl + 1))
         else:
-            p2.append(XA + X_ZERO)
+            p2.append(S + O_D + 4)
+    sh = lambda arr, o: [None if a is None else a + o for a in arr]
     tot = conflict_cycles(p2, 1)
-    tot += conflict_cycles(p3, 1) + conflict_cycles([a + 2 for a in p3], 1)
+    tot += conflict_cycles(p3, 1) + conflict_cycles(sh(p3, 2), 1)
     for g in range(6):
-        tot += conflict_cycles([a + GS * g for a in p1], 1)
+        tot += conflict_cycles(sh(p1, GS * g), 1)
     return tot
 
 
@@ -157,7 +162,7 @@ def detail():
             vl = lane & 7
             tv.append(XA + X_UNIT + 4 * (vl - 2) if vl in (2, 3) else S + GS * vcol(vl) + G_XY)
             dg.append(S + O_D + vl if vl < 2 else (S + O_D + vl - 4 if vl >= 6 else XA + X_ZERO))
-            ab.append(S + koff(vl - 2) if vl >= 2 else S + O_INV + 2 * vl)
+            ab.append(S + koff(vl - 2) if vl >= 2 else S + (O_INV0 if vl == 0 else O_INV1))
         print(k, (2 * S) % 64, [conflict_cycles([a + o for a in tv], 1) for o in range(3)], conflict_cycles(dg, 1),
               [conflict_cycles([a + o for a in ab], 1) for o in range(2)])
 

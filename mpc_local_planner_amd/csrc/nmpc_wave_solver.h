@@ -418,7 +418,9 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
             }
             const double mu = w.sum(mu_loc) / mcount;
             const double cmax = w.max(c_loc);
+#ifndef NMPC_PROF_FIXED_ITERS      // (profiling variants that skip sweeps produce garbage, NaN included)
             if (!(mu == mu)) { qp_status = 1; break; }
+#endif
 #ifdef NMPC_PROF_FIXED_ITERS
             if (it >= NMPC_PROF_FIXED_ITERS) { qp_status = 0; break; }
 #else
@@ -535,30 +537,32 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 const D2 v01 = ld2(pBotI);
                 const double v2 = pBotI[2];
                 // stage data (independent of the recursion) is fetched one stage ahead, so that the
-                // loads that ARE on the serial path (Pt row, Mt column, input rows) never queue behind it
-                D2 t01 = ld2(tj), b01 = ld2(bj), u01 = ld2(ti);
-                double t2 = tj[2], b2 = bj[2], u2 = ti[2], tbv = *tb;
-#pragma unroll 2
-                for (int k = (NMPC_PROF_SKIP & 1) ? -1 : N - 1; k >= 0; --k) {
+                // loads that ARE on the serial path (Pt row, Mt column, input rows) never queue behind it;
+                // two register sets take turns (loop body written out twice: no register moves)
+                struct StageData { D2 t01, b01, u01; double t2, b2, u2, tbv; };
+                StageData sdA, sdB;
+                sdA.t01 = ld2(tj); sdA.b01 = ld2(bj); sdA.u01 = ld2(ti);
+                sdA.t2 = tj[2]; sdA.b2 = bj[2]; sdA.u2 = ti[2]; sdA.tbv = *tb;
+                auto factor_stage = [&](const StageData &c, StageData &n) {
                     const D2 r01 = ld2(pProw), r23 = ld2(pProw + 2), r45 = ld2(pProw + 4);
                     const double r6 = pProw[6];
                     w.sched_fence();
                     // phase 1: Mt[m][j] = Pt[m][0..5] . BAt[0..5][j] + p[m] [j == 8]
-                    double accA = r6 * e8, accB = r01.y * t01.y;
-                    accA = fma(r01.x, t01.x, accA); accB = fma(r23.y, b01.x, accB);
-                    accA = fma(r23.x, t2, accA);    accB = fma(r45.y, b2, accB);
-                    accA = fma(r45.x, b01.y, accA);
+                    double accA = r6 * e8, accB = r01.y * c.t01.y;
+                    accA = fma(r01.x, c.t01.x, accA); accB = fma(r23.y, c.b01.x, accB);
+                    accA = fma(r23.x, c.t2, accA);    accB = fma(r45.y, c.b2, accB);
+                    accA = fma(r45.x, c.b01.y, accA);
                     *pMw = accA + accB;
                     w.wsync();
                     // phase 2: Ht[i][j] = cost[i][j] + BAt[0..5][i] . Mt[0..5][j]
                     const D2 m01 = ld2(pMr), m23 = ld2(pMr + 2), m45 = ld2(pMr + 4);
                     // data of stage k-1 (at k = 0 this reads the pseudo-stage: valid memory, not used)
                     tj -= sTopJ; bj -= sBotJ; ti -= sTopI; tb -= sTab;
-                    const D2 nt01 = ld2(tj), nb01 = ld2(bj), nu01 = ld2(ti);
-                    const double nt2 = tj[2], nb2 = bj[2], nu2 = ti[2], ntb = *tb;
+                    n.t01 = ld2(tj); n.b01 = ld2(bj); n.u01 = ld2(ti);
+                    n.t2 = tj[2]; n.b2 = bj[2]; n.u2 = ti[2]; n.tbv = *tb;
                     w.sched_fence();
-                    double HvA = fma(u01.x, m01.x, hconst + tbv), HvB = u01.y * m01.y;
-                    HvA = fma(u2, m23.x, HvA);    HvB = fma(v01.x, m23.y, HvB);
+                    double HvA = fma(c.u01.x, m01.x, hconst + c.tbv), HvB = c.u01.y * m01.y;
+                    HvA = fma(c.u2, m23.x, HvA);  HvB = fma(v01.x, m23.y, HvB);
                     HvA = fma(v01.y, m45.x, HvA); HvB = fma(v2, m45.y, HvB);
                     const double Hv = HvA + HvB;
                     *pHw = Hv;
@@ -578,7 +582,12 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     st2(kw, K0, K1);
                     w.wsync();
                     kw -= sKw;
-                    t01 = nt01; b01 = nb01; u01 = nu01; t2 = nt2; b2 = nb2; u2 = nu2; tbv = ntb;
+                };
+#pragma unroll 1
+                for (int k = (NMPC_PROF_SKIP & 1) ? -1 : N - 1; k >= 0; k -= 2) {
+                    factor_stage(sdA, sdB);
+                    if (k == 0) break;
+                    factor_stage(sdB, sdA);
                 }
             }
 

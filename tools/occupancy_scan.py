@@ -11,9 +11,11 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = os.path.join(ROOT, "build_variants", sys.argv[1] if len(sys.argv) > 1 else "libnmpc_full10.so")
+name = sys.argv[1] if len(sys.argv) > 1 else "libnmpc_full10.so"
+lib = os.path.join(ROOT, "build_variants", name)
+batches = [int(b) for b in sys.argv[2].split(",")] if len(sys.argv) > 2 else (256, 512, 1024, 2048, 4096, 8192)
 res = {}
-for B in (256, 512, 1024, 2048, 4096, 8192):
+for B in batches:
     env = dict(os.environ, NMPC_HIP_LIB=lib)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extras",
                           "--steps", "20", "--warmup", "3", "--batch", str(B)], env=env, capture_output=True,
@@ -25,4 +27,4 @@ for B in (256, 512, 1024, 2048, 4096, 8192):
         res[B] = out.stderr[-300:]
     print(B, res[B], flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(res, open(os.path.join(ROOT, "gpurun_out", "occupancy_scan.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "occupancy_scan_%s.json" % name.replace(".so", "")), "w"), indent=1)

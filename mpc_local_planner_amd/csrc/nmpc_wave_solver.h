@@ -574,8 +574,9 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     const D2 hj = ld2(pHj), hi = ld2(pHi);
                     w.sched_fence();
                     const double rdet = w.rcp(H00 * H11 - H01 * H01);
-                    const double i00 = H11 * rdet, i01 = -H01 * rdet, i11 = H00 * rdet;
-                    const double K0 = -(i00 * hj.x + i01 * hj.y), K1 = -(i01 * hj.x + i11 * hj.y);
+                    // rows of -inv(Huu) (the signs ride on the multiplies): K = -inv(Huu) Hu
+                    const double n00 = -H11 * rdet, n01 = H01 * rdet, n11 = -H00 * rdet;
+                    const double K0 = fma(n00, hj.x, n01 * hj.y), K1 = fma(n01, hj.x, n11 * hj.y);
                     const double Pn = Hv + hi.x * K0 + hi.y * K1;
                     *pPw1 = Pn;
                     *pPw2 = Pn;

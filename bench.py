@@ -30,7 +30,7 @@ HBM_PEAK_GBPS = 8000.0
 # cannot be read from inside this process): 2 x FETCH_SIZE (gfx950 tallies 128-B requests as 64 B;
 # the factor is calibrated for wide streaming reads only, so this is an upper bound) + WRITE_SIZE,
 # both in KiB as rocprofv3 reports them.
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1d", "pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1e", "pmc_summary.json")
 
 
 def pmc_traffic_bytes_per_launch():

@@ -293,6 +293,38 @@ def test_full_size_batch_properties():
     s.close()
 
 
+def test_config3_per_gpu_share_properties():
+    """One GPU's share of BASELINE config 3 (1,048,576 instances over 8 GPUs = 131,072 per GPU,
+    N = 40; the launch order is the identity at this size): all converge, bounds hold, x_0 is the
+    measurement, the generator's block structure holds (instances [start, start+n) equal the same
+    rows of a bigger draw), and a strided sample agrees with the oracle."""
+    N, B = 40, 131072
+    x0, p = sc.config2(B)
+    xs, ps = sc.config2(64, start=B - 64)
+    assert np.array_equal(xs, x0[-64:]) and np.array_equal(ps, p[-64:])
+    s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
+    s.set_x0(x0)
+    s.set_params(p)
+    s.solve(B)
+    g = s.get(B)
+    assert (g["status"] == 0).all()
+    x, u = g["x"], g["u"]
+    c = capi.default_config(N, 0.35)
+    eps = 1e-9
+    assert (u[:, :, 0] >= c.lbu[0] - eps).all() and (u[:, :, 0] <= c.ubu[0] + eps).all()
+    assert (u[:, :, 1] >= c.lbu[1] - eps).all() and (u[:, :, 1] <= c.ubu[1] + eps).all()
+    assert (x[:, 1:N, 4] >= c.lbx[0] - eps).all() and (x[:, 1:N, 4] <= c.ubx[0] + eps).all()
+    assert (x[:, 1:N, 5] >= c.lbx[1] - eps).all() and (x[:, 1:N, 5] <= c.ubx[1] + eps).all()
+    assert np.abs(x[:, 0, :] - x0).max() == 0.0
+    ctrl = s.get_controls(B)
+    assert np.array_equal(ctrl[:, 0:2], u[:, 0, :]) and np.array_equal(ctrl[:, 2:4], x[:, 1, 4:6])
+    assert np.array_equal(ctrl[:, 5], g["status"] + 16.0 * g["ipm_iters"])
+    idx = np.arange(7, B, 1024)
+    xo, uo, _, io = orc.rti_batch(_ocfg(N), x0[idx], p[idx])
+    assert_parity(g, xo, uo, io, sel=idx)
+    s.close()
+
+
 def test_launch_order_does_not_change_results(monkeypatch):
     """The longest-first launch order (nmpc_order_kernel, sorted by the previous call's iteration
     counts) only permutes which workgroup solves which instance: trajectories, status and

@@ -91,3 +91,25 @@ def test_emulated_wave_sqp_mode_iteration_limit():
         assert st.status == 2 and g["status"][i] == 2
         assert g["sqp_iters"][i] == st.sqp_iters == 2
         assert np.abs(g["x"][i] - xo).max() <= 1e-7 and np.abs(g["u"][i] - uo).max() <= 1e-7
+
+
+def test_emulated_wave_failure_paths_match_the_oracle():
+    """Status 1 (NaN in the measurement: the iterate is left as it was) and status 4 (interior-point
+    iteration limit: the step is still taken, as acados returns the failed trajectory,
+    src/AcadosSolver.cpp:56-59) -- same status, same iterate as the oracle; other instances of the
+    batch are not affected."""
+    N, B = 20, 4
+    cfg = orc.default_config(N, 0.35)
+    x0, p = sc.config2(B)
+    x0[1, 3] = np.nan
+    g = emu.solve_batch(cfg, x0, p)
+    xo, uo, so, io = orc.rti_batch(cfg, x0, p)
+    assert g["status"].tolist() == so.tolist() == [0, 1, 0, 0]
+    ok = so == 0
+    assert _err(dict(x=g["x"][ok], u=g["u"][ok]), xo[ok], uo[ok]).max() <= 1e-7
+    x0, p = sc.config2(B)
+    cfg3 = orc.default_config(N, 0.35, ipm_max_iter=3)
+    g = emu.solve_batch(cfg3, x0, p)
+    xo, uo, so, io = orc.rti_batch(cfg3, x0, p)
+    assert (g["status"] == 4).all() and (so == 4).all() and (g["ipm_iters"] == 3).all()
+    assert _err(g, xo, uo).max() <= 1e-9

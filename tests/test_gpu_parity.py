@@ -132,6 +132,51 @@ def test_reset_mask_and_partial_batch():
     s.close()
 
 
+def test_failed_instances_report_and_restart_cold():
+    """Failure protocol of Solver::solve (src/AcadosSolver.cpp:56-59: status != 0 -> reInit, the
+    failed trajectory is still returned): a NaN measurement gives status 1 for that instance only;
+    an interior-point iteration limit gives status 4 with the oracle's iterate; after either, the
+    next call of that instance starts from the cold guess again while the others stay warm."""
+    N, B = 40, 64
+    x0, p = sc.config2(B)
+    bad = x0.copy()
+    bad[5, 3] = np.nan
+    s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
+    s.set_x0(bad)
+    s.set_params(p)
+    s.solve(B)
+    g = s.get(B)
+    assert g["status"][5] == 1 and (np.delete(g["status"], 5) == 0).all()
+    ctrl = s.get_controls(B)
+    assert int(ctrl[5, 5]) % 16 == 1
+    s.set_x0(x0)                      # a sane measurement again
+    s.solve(B)
+    g2 = s.get(B)
+    assert (g2["status"] == 0).all()
+    ocfg = _ocfg(N)
+    xc, uc, _, _ = orc.rti_batch(ocfg, x0, p)                                      # cold
+    xw, uw, _, _ = orc.rti_batch(ocfg, x0, p, xc.copy(), uc.copy(), cold=False)    # cold + warm
+    one = dict(x=g2["x"][5:6], u=g2["u"][5:6])
+    assert np.abs(one["x"] - xc[5:6]).max() <= 1e-7 and np.abs(one["u"] - uc[5:6]).max() <= 1e-7
+    keep = np.arange(B) != 5
+    assert_parity(dict(x=g2["x"][keep], u=g2["u"][keep]), xw[keep], uw[keep])
+    s.close()
+    c = capi.default_config(N, 0.35)
+    c.ipm_max_iter = 3
+    s = capi.BatchSolver(cfg=c, capacity=B)
+    s.set_x0(x0)
+    s.set_params(p)
+    s.solve(B)
+    g = s.get(B)
+    xo, uo, so, io = orc.rti_batch(orc.config_like(c), x0, p)
+    assert (g["status"] == 4).all() and (so == 4).all() and (g["ipm_iters"] == 3).all()
+    assert np.abs(g["x"] - xo).max() <= 1e-9 and np.abs(g["u"] - uo).max() <= 1e-9
+    s.solve(B)                         # status 4 -> cold again: the same failed step from the same start
+    g2 = s.get(B)
+    assert (g2["status"] == 4).all() and np.array_equal(g2["x"], g["x"]) and np.array_equal(g2["u"], g["u"])
+    s.close()
+
+
 def test_per_instance_weights_and_bounds():
     N, B = 40, 64
     x0, p = sc.config2(B)

@@ -89,7 +89,7 @@ constexpr int G_XY = 2;         //   rows X,Y (pair), row psi at +2
 constexpr int O_E = 36;         // (K0[X],K1[X]), (K0[Y],K1[Y])
 constexpr int O_KFF = 40;       // (kff0,kff1)
 constexpr int O_INV0 = 42;      // rows of -inv(Huu): (-i00,-i01) here, (-i01,-i11) at O_INV1
-constexpr int O_D = 44;         // slot k: rb_k as [0,1,2,-,3,4,5,-] -> z_{k+1}[8] = du,dx -> dG_k[4]
+constexpr int O_D = 44;         // slot k: rb_k as [0,1,2,-,3,4,5,-] -> z_{k+1}[8] = du,dx -> dG_k[4], 0, 0
 constexpr int O_INV1 = 52;
 // The order of these tail blocks is chosen so that every per-stage read of the sweeps is free of
 // LDS bank conflicts (tools/lds_conflicts.py): the gain pairs, the rows of -inv(Huu) and the start

@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # = 1/2 of the 157.3 TF fp32 vector spec (MI355X_MICROARCH.md); also the fp64 MFMA peak
+FP64_FMA_MEASURED_TFLOPS = 67.3  # chip-wide v_fma_f64 loop on this pool (tools/micro/fma64_peak.hip)
 HBM_PEAK_GBPS = 8000.0
 # HBM bytes per 4096-instance launch come from the PMC passes committed under profiles/ (rocprofv3
 # cannot be read from inside this process): 2 x FETCH_SIZE (gfx950 tallies 128-B requests as 64 B;
@@ -286,6 +287,7 @@ def main():
                     "no MFMA-shaped work).  Measured binding resources are the LDS pipe and serial-recursion "
                     "latency, see DESIGN.md section 5; the HBM view is in 'hbm'",
             "kernel_ms": kernel_ms, "flops_per_solve": flops_per_solve(N, n_ipm_cold),
+            "peak_measured_fma64": FP64_FMA_MEASURED_TFLOPS,
             "hbm": {"bound": "hbm", "achieved": by / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": by / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                     "bytes_per_solve": bytes_per_solve(N, False)},

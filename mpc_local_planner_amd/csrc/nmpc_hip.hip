@@ -448,7 +448,7 @@ int nmpc_default_config(nmpc_config *c, int N, double dt)
 }
 
 int nmpc_config_from_file(const char *path, nmpc_config *cfg, nmpc_run_params *run)
-{
+try {
     if (!path || !cfg) return NMPC_EINVAL;
     FILE *f = fopen(path, "r");
     if (!f) {
@@ -537,6 +537,12 @@ int nmpc_config_from_file(const char *path, nmpc_config *cfg, nmpc_run_params *r
     cfg->lbx[1] = r[3][0]; cfg->ubx[1] = r[3][1];
     if (run) *run = rp;
     return NMPC_OK;
+} catch (const std::bad_alloc &) {   // host containers: no exception may cross the C ABI
+    snprintf(g_err, sizeof(g_err), "nmpc_config_from_file: out of host memory");
+    return NMPC_ENOMEM;
+} catch (...) {
+    snprintf(g_err, sizeof(g_err), "nmpc_config_from_file: unexpected exception");
+    return NMPC_EINVAL;
 }
 
 static int fill_defaults(nmpc_handle *h, bool weights, bool bounds)
@@ -696,7 +702,7 @@ int nmpc_reset(nmpc_handle *h, const uint8_t *mask, int B)
 }
 
 int nmpc_set_iterate(nmpc_handle *h, const double *x, const double *u, int B)
-{
+try {
     if (!h || !x || !u || B <= 0 || B > h->capacity) return NMPC_EINVAL;
     HIP_TRY(hipSetDevice(h->device));
     const size_t N = (size_t)h->cfg.N, N1 = N + 1;
@@ -713,6 +719,12 @@ int nmpc_set_iterate(nmpc_handle *h, const double *x, const double *u, int B)
     HIP_TRY(hipMemsetAsync(h->d_reset, 0, (size_t)B, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return NMPC_OK;
+} catch (const std::bad_alloc &) {   // host containers: no exception may cross the C ABI
+    snprintf(g_err, sizeof(g_err), "nmpc_set_iterate: out of host memory");
+    return NMPC_ENOMEM;
+} catch (...) {
+    snprintf(g_err, sizeof(g_err), "nmpc_set_iterate: unexpected exception");
+    return NMPC_EINVAL;
 }
 
 int nmpc_solve(nmpc_handle *h, int B, int mode, int max_iter, double tol)
@@ -770,7 +782,7 @@ int nmpc_sync(nmpc_handle *h)
 
 int nmpc_get(nmpc_handle *h, int B, double *x, double *u, int32_t *status, double *cost,
              int32_t *ipm_iters, int32_t *sqp_iters)
-{
+try {
     if (!h || B <= 0 || B > h->capacity) return NMPC_EINVAL;
     HIP_TRY(hipSetDevice(h->device));
     const size_t N = (size_t)h->cfg.N, N1 = N + 1;
@@ -794,6 +806,12 @@ int nmpc_get(nmpc_handle *h, int B, double *x, double *u, int32_t *status, doubl
             }
     }
     return NMPC_OK;
+} catch (const std::bad_alloc &) {   // host containers: no exception may cross the C ABI
+    snprintf(g_err, sizeof(g_err), "nmpc_get: out of host memory");
+    return NMPC_ENOMEM;
+} catch (...) {
+    snprintf(g_err, sizeof(g_err), "nmpc_get: unexpected exception");
+    return NMPC_EINVAL;
 }
 
 int nmpc_get_controls(nmpc_handle *h, int B, double *ctrl)
@@ -875,7 +893,7 @@ int nmpc_get_world_path(nmpc_handle *h, int B, double *xy)
 
 int nmpc_closed_loop(nmpc_handle *h, int B, int steps, double dt_plant, double steering_ratio,
                      double *world_state, const double *pitch_vref, double *trace, int32_t *n_failed)
-{
+try {
     if (!h || !world_state || !pitch_vref || B <= 0 || B > h->capacity || steps < 1 || !h->d_track ||
         !(dt_plant > 0.0) || !(steering_ratio != 0.0))
         return NMPC_EINVAL;
@@ -908,6 +926,12 @@ int nmpc_closed_loop(nmpc_handle *h, int B, int steps, double dt_plant, double s
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (n_failed) *n_failed = failed;
     return NMPC_OK;
+} catch (const std::bad_alloc &) {   // host containers: no exception may cross the C ABI
+    snprintf(g_err, sizeof(g_err), "nmpc_closed_loop: out of host memory");
+    return NMPC_ENOMEM;
+} catch (...) {
+    snprintf(g_err, sizeof(g_err), "nmpc_closed_loop: unexpected exception");
+    return NMPC_EINVAL;
 }
 
 void *nmpc_device_ptr(nmpc_handle *h, int which)

@@ -175,6 +175,12 @@ struct GpuWave {
               [adg] "v"(lds_addr(dg)), [aab] "v"(lds_addr(ab)), [kfw] "v"(lds_addr(kfw))
             : "memory");
     }
+    // issue priority of the wave while it runs the serial sweeps: the other wave of the SIMD, when it is
+    // in its element-wise phase, has independent work to fill the gaps with (+0.3 % cold, +1.2 % warm)
+    __device__ __forceinline__ void sweep_priority(bool on)
+    {
+        if (on) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+    }
     // after a sweep: nothing of it is still in flight
     __device__ __forceinline__ void sweep_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     // acc + (src of lane C of the caller's 16-lane row) * coef, fused (single use outside the sweeps' asm)

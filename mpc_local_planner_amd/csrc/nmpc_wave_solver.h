@@ -468,6 +468,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
             w.sync();
 
             // ---- factor sweep, k = N-1 .. 0 (augmented Riccati recursion), first wave only
+            w.sweep_priority(true);
             if (w.sweep_wave()) {
                 // per-lane LDS pointers of this sweep, recomputed here (a few dozen integer ops per
                 // interior-point iteration) instead of living in ~45 registers through the whole solve;
@@ -694,6 +695,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                         for (int m = 0; m < 6; ++m) ct[O_D + 2 + m] = 0.0;
                     }
                 }
+                w.sweep_priority(false);
                 w.sync();
                 // ---- stage layout: pick up the direction of this node (slot node-1 holds z_node)
                 double dzl[8];
@@ -753,6 +755,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                         st2(sl + 4, 0.0, 0.0);     // the zero operand of the second pass (read next to dG)
                     }
                     w.sync();
+                    w.sweep_priority(true);
                 } else {
                     // E-C: combined direction, step length, update
                     double r_loc = 0.0;

@@ -417,14 +417,16 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 c_loc = fmax(c_loc, fmax(fmin(tl[q], ll[q]), fmin(tu[q], lu[q])));
             }
             const double mu = w.sum(mu_loc) / mcount;
-            const double cmax = w.max(c_loc);
+            // the pairwise test only decides once the averages have converged (uniform over the instance)
+            const bool near_end = it > 0 && mu <= pb.tol_mu && lin_scale <= pb.tol_lin;
+            const double cmax = near_end ? w.max(c_loc) : 1.0;
 #ifndef NMPC_PROF_FIXED_ITERS      // (profiling variants that skip sweeps produce garbage, NaN included)
             if (!(mu == mu)) { qp_status = 1; break; }
 #endif
 #ifdef NMPC_PROF_FIXED_ITERS
             if (it >= NMPC_PROF_FIXED_ITERS) { qp_status = 0; break; }
 #else
-            if (it > 0 && mu <= pb.tol_mu && lin_scale <= pb.tol_lin && cmax <= pb.tol_comp) { qp_status = 0; break; }
+            if (near_end && cmax <= pb.tol_comp) { qp_status = 0; break; }
 #endif
             if (it >= pb.ipm_max_iter) { qp_status = (mu <= 1e-8 && lin_scale <= 1e-8) ? 0 : 4; break; }
             {

@@ -194,6 +194,13 @@ struct GpuWave {
     }
     // keep the loads issued above this point together (one wait instead of one per load)
     __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+    // a value that is the same on every lane, moved to scalar registers
+    __device__ __forceinline__ double uniform(double v)
+    {
+        const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+        const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+        return __hiloint2double(hi, lo);
+    }
     // value of lane `src` of the calling wave (uniform)
     __device__ __forceinline__ double readlane(double v, int src)
     {
@@ -218,8 +225,9 @@ struct GpuWave {
     template <int CTRL>
     __device__ __forceinline__ static double dpp(double v)
     {
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+        // every lane has a valid source under these controls (full rows, full EXEC): no "old" value to set up
+        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
         return __hiloint2double(hi, lo);
     }
     // partial results of the waves meet in LDS; slots alternate so one barrier per call is enough

@@ -242,12 +242,15 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
         ub_[0] = (io.cold || !act) ? 0.0 : t[6];
         ub_[1] = (io.cold || !act) ? 0.0 : t[7];
     }
-    const double mcount = (double)(4 * N + 4 * (N - 1));
+    const double inv_mcount = w.uniform(w.rcp((double)(4 * N + 4 * (N - 1))));   // 1 / number of slack-multiplier pairs
     double lb[4], ub[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { lb[q] = io.bnd[q]; ub[q] = io.bnd[4 + q]; }
-    const double R00 = h * io.W[5], R11 = h * io.W[6], Q11 = h * io.W[0], Q22 = h * io.W[1],
-                 Q33 = h * io.W[2], Q44 = h * io.W[3], Q55 = h * io.W[4];
+    // values that are the same on every lane are handed to the scalar registers (w.uniform): fp64
+    // arithmetic leaves them in vector registers otherwise, and those are what this kernel is short of
+    const double R00 = w.uniform(h * io.W[5]), R11 = w.uniform(h * io.W[6]), Q11 = w.uniform(h * io.W[0]),
+                 Q22 = w.uniform(h * io.W[1]), Q33 = w.uniform(h * io.W[2]), Q44 = w.uniform(h * io.W[3]),
+                 Q55 = w.uniform(h * io.W[4]);
 
     double *const last = stg + (N - 1) * ST;   // the backward sweeps start at stage N-1
 
@@ -316,7 +319,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 st2(c - G_XY + 1 * GS + G_K, 0.0, 0.0);
             }
             if (!tables_ready) {   // constant rows (v,delta,thr) of [B A]: identical on every lane
-                a33 = aV[1]; a35 = aV[3]; b31 = aV[5];   // functions of dt only
+                a33 = w.uniform(aV[1]); a35 = w.uniform(aV[3]); b31 = w.uniform(aV[5]);   // functions of dt only
                 if (tid == 0) {
                     double *c = ct + G_XY;          // rows v,delta,thr in the (X,Y,psi) positions of each group
                     c[0 * GS] = 0.0; c[0 * GS + 1] = h;   c[0 * GS + 2] = 0.0;     // u0
@@ -416,7 +419,8 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 // pairwise complementarity (masked pairs hold t = 1, lambda = 0)
                 c_loc = fmax(c_loc, fmax(fmin(tl[q], ll[q]), fmin(tu[q], lu[q])));
             }
-            const double mu = w.sum(mu_loc) / mcount;
+            // (a divide is an eleven-instruction dependent sequence on gfx950: reciprocal and multiply instead)
+            const double mu = w.sum(mu_loc) * inv_mcount;
             // the pairwise test only decides once the averages have converged (uniform over the instance)
             const bool near_end = it > 0 && mu <= pb.tol_mu && lin_scale <= pb.tol_lin;
             const double cmax = near_end ? w.max(c_loc) : 1.0;
@@ -738,8 +742,8 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     for (int q = 0; q < 4; ++q)
                         ma += (tl[q] + a_aff * dtl[q]) * (ll[q] + a_aff * dll[q]) +
                               (tu[q] + a_aff * dtu[q]) * (lu[q] + a_aff * dlu[q]);
-                    mu_aff = w.sum(ma) / mcount;
-                    const double sr = mu_aff / mu;
+                    mu_aff = w.sum(ma) * inv_mcount;
+                    const double sr = mu_aff * w.rcp(mu);
                     smu = sr * sr * sr * mu;
                     // Mehrotra's second-order term, damped when the affine step is almost fully
                     // blocked (undamped it over-corrects and the iteration can cycle)

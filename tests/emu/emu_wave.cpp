@@ -113,6 +113,7 @@ struct EmuWave {
     }
     void sweep_drain() {}
     void sweep_priority(bool) {}
+    double uniform(double v) { return v; }
     void bwd_fetch(const double *tv, const double *dg, const double *ab, double (&d)[6])
     {
         d[0] = tv[0]; d[1] = tv[1]; d[2] = tv[2];

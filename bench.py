@@ -192,8 +192,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # NMPC_BENCH_FORCE_DIST=1 runs the collective path with a single rank too (rehearsal on a one-GPU box)
+    dist_on = world > 1 or os.environ.get("NMPC_BENCH_FORCE_DIST") == "1"
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     N, B = args.horizon, args.batch
     solver = capi.BatchSolver(N=N, dt=0.35, capacity=B, device=local_rank)
@@ -209,27 +213,54 @@ def main():
         def __init__(self, ptr, n):
             self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False),
                                              "version": 2}
-    ctrl_local = torch.as_tensor(_Arr(solver.device_ptr(0), B * 6), device=f"cuda:{local_rank}").reshape(B, 6)
+    dev = torch.device("cuda", local_rank)
+    # The gather of step s overlaps the solve of step s+1: the solves write their control records
+    # alternately into two device buffers (nmpc_set_controls_device), a side stream runs the
+    # collective on the buffer a solve has just filled, and the solver's stream only waits for the
+    # collective that last read the buffer it is about to overwrite.  No host synchronisation and
+    # no copy per step.
+    solve_stream = torch.cuda.ExternalStream(int(stream), device=dev)
+    comm_stream = torch.cuda.Stream(device=dev)
+    records = [torch.zeros(B * 6, dtype=torch.float64, device=dev) for _ in range(2)]
+    gathered = [torch.empty(world * B * 6, dtype=torch.float64, device=dev) for _ in range(2)]
+    solved = [torch.cuda.Event() for _ in range(2)]
+    gather_done = [torch.cuda.Event() for _ in range(2)]
+    n_gathers = [0]
+
+    def before_gathered_solve():
+        i = n_gathers[0] & 1
+        if n_gathers[0] >= 2:
+            solve_stream.wait_event(gather_done[i])         # the collective of two steps ago has read records[i]
+        solver.set_controls_device(records[i].data_ptr())
+
+    def enqueue_gather():
+        i = n_gathers[0] & 1
+        solved[i].record(solve_stream)
+        comm_stream.wait_event(solved[i])
+        with torch.cuda.stream(comm_stream):
+            dist.all_gather_into_tensor(gathered[i], records[i])
+            gather_done[i].record(comm_stream)
+        n_gathers[0] += 1
 
     def barrier():
         solver.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
 
     def run(steps, cold, gather, events=None):
         for s in range(steps):
             if cold:
                 solver.reset(None, B)
+            if gather and dist_on:
+                before_gathered_solve()
             if events is not None:
                 hip.record(events[2 * s], stream)
             solver.solve(B)
             if events is not None:
                 hip.record(events[2 * s + 1], stream)
-            if gather and world > 1:
-                solver.sync()                       # records complete before RCCL reads them
-                sharding.gather_controls(ctrl_local, total=world * B)
-                torch.cuda.synchronize()            # ... and gathered before the next solve overwrites them
+            if gather and dist_on:
+                enqueue_gather()
 
     def timed(steps, cold, gather, with_events=False):
         events = [hip.event() for _ in range(2 * steps)] if with_events else None
@@ -241,15 +272,23 @@ def main():
         kms = None
         if events:
             kms = float(np.mean([hip.elapsed_ms(events[2 * s], events[2 * s + 1]) for s in range(steps)]))
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        if dist_on:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, kms
 
-    gather = world > 1
+    gather = dist_on
     run(args.warmup, True, gather)
     dt_main, kernel_ms = timed(args.steps, True, gather, with_events=True)
+    if dist_on:
+        # the last gather must hold this rank's records of the last gathered step in this rank's block
+        last = gathered[(n_gathers[0] - 1) & 1].reshape(world, B, 6)
+        if not torch.equal(last[rank], records[(n_gathers[0] - 1) & 1].reshape(B, 6)):
+            raise SystemExit("all-gather returned records that differ from this rank's own")
+        if not np.array_equal(solver.get_controls(B), records[(n_gathers[0] - 1) & 1].reshape(B, 6).cpu().numpy()):
+            raise SystemExit("control records did not land in the caller's device buffer")
+        solver.set_controls_device(None)
     g = solver.get(B)
     n_ipm_cold = float(g["ipm_iters"].mean())
     ok_cold = float((g["status"] == 0).mean())
@@ -260,7 +299,7 @@ def main():
     gw = solver.get(B)
     n_ipm_warm = float(gw["ipm_iters"].mean())
     dt_nogather = None
-    if world > 1:
+    if dist_on:
         run(2, True, False)
         dt_nogather, _ = timed(args.steps, True, False)
 
@@ -306,7 +345,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     solver.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

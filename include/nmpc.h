@@ -90,6 +90,12 @@ int nmpc_set_params(nmpc_handle *h, const double *p, int B);
  * is host-only. */
 int nmpc_set_inputs_device(nmpc_handle *h, const double *d_x0, const double *d_p, int B);
 
+/* Control records of the following solves go to the caller's device buffer d_ctrl[capacity][6]
+ * (NULL: back to the handle's own buffer); nmpc_get_controls, nmpc_closed_loop and
+ * nmpc_device_ptr(h, 0) follow.  Lets a consumer alternate between two buffers, e.g. to all-gather
+ * the records of one solve (RCCL) while the next solve runs.  No reference counterpart (host-only). */
+int nmpc_set_controls_device(nmpc_handle *h, double *d_ctrl);
+
 /* Per-instance cost weights W[B][7] / bounds bnd[B][8] = lbu0,lbu1,lbx4,lbx5,ubu0,ubu1,ubx4,ubx5
  * (the reference bakes one set into generated code, mpcPathTracking.py:103-115; the generic
  * acados setters ocp_nlp_cost_model_set / ocp_nlp_constraints_model_set are the counterpart).

@@ -36,7 +36,7 @@ EXPORTS = [
     "nmpc_default_config", "nmpc_config_from_file", "nmpc_create", "nmpc_destroy", "nmpc_set_x0", "nmpc_set_params",
     "nmpc_set_inputs_device", "nmpc_set_weights", "nmpc_set_bounds", "nmpc_reset", "nmpc_set_iterate",
     "nmpc_solve",
-    "nmpc_sync", "nmpc_get", "nmpc_get_controls", "nmpc_device_ptr", "nmpc_stream",
+    "nmpc_sync", "nmpc_get", "nmpc_get_controls", "nmpc_device_ptr", "nmpc_stream", "nmpc_set_controls_device",
     "nmpc_capacity", "nmpc_horizon", "nmpc_last_error",
     "nmpc_set_track", "nmpc_frontend", "nmpc_get_frontend", "nmpc_get_world_path", "nmpc_closed_loop",
 ]
@@ -76,6 +76,7 @@ def lib():
     l.nmpc_get_controls.argtypes = [vp, C.c_int, dp]
     l.nmpc_device_ptr.argtypes = [vp, C.c_int]
     l.nmpc_device_ptr.restype = vp
+    l.nmpc_set_controls_device.argtypes = [vp, vp]
     l.nmpc_stream.argtypes = [vp]
     l.nmpc_stream.restype = vp
     l.nmpc_capacity.argtypes = [vp]
@@ -247,6 +248,10 @@ class BatchSolver:
 
     def device_ptr(self, which):
         return lib().nmpc_device_ptr(self._h, which)
+
+    def set_controls_device(self, ptr):
+        """Device pointer (int) of a [capacity][6] float64 buffer for the control records, or None."""
+        check(lib().nmpc_set_controls_device(self._h, C.c_void_p(ptr) if ptr else None), "nmpc_set_controls_device")
 
     def stream(self):
         return lib().nmpc_stream(self._h)

@@ -428,6 +428,7 @@ struct nmpc_handle {
     unsigned char *d_reset, *d_mask;
     bool ordered;                 // launch longest-expected instances first (NMPC_SCHEDULE=0 turns it off)
     const double *in_x0, *in_p;   // what the kernel reads (own buffers or caller's device buffers)
+    double *out_ctrl;             // where the control records go (own buffer or the caller's device buffer)
     std::vector<double> h_traj;
     // path front-end / closed loop (allocated by nmpc_set_track)
     double *d_track = nullptr, *d_ws = nullptr, *d_pv = nullptr, *d_rot = nullptr, *d_xy = nullptr;
@@ -637,6 +638,7 @@ int nmpc_create(const nmpc_config *cfg, int capacity, int device, nmpc_handle **
     }
     h->in_x0 = h->d_x0;
     h->in_p = h->d_p;
+    h->out_ctrl = h->d_ctrl;
     *out = h;
     return NMPC_OK;
 }
@@ -686,6 +688,13 @@ int nmpc_set_inputs_device(nmpc_handle *h, const double *d_x0, const double *d_p
     if (!h || !d_x0 || !d_p || B <= 0 || B > h->capacity) return NMPC_EINVAL;
     h->in_x0 = d_x0;
     h->in_p = d_p;
+    return NMPC_OK;
+}
+
+int nmpc_set_controls_device(nmpc_handle *h, double *d_ctrl)
+{
+    if (!h) return NMPC_EINVAL;
+    h->out_ctrl = d_ctrl ? d_ctrl : h->d_ctrl;
     return NMPC_OK;
 }
 
@@ -762,7 +771,7 @@ int nmpc_solve(nmpc_handle *h, int B, int mode, int max_iter, double tol)
     a.pb.sqp_tol = tol;
     a.B = B;
     a.x0 = h->in_x0; a.p = h->in_p; a.W = h->d_W; a.bnd = h->d_bnd;
-    a.traj = h->d_traj; a.ctrl = h->d_ctrl; a.cost = h->d_cost;
+    a.traj = h->d_traj; a.ctrl = h->out_ctrl; a.cost = h->d_cost;
     a.status = h->d_status; a.iters = h->d_iters; a.sqp_iters = h->d_sqp;
     a.reset = h->d_reset;
     a.order = nullptr;
@@ -832,7 +841,7 @@ int nmpc_get_controls(nmpc_handle *h, int B, double *ctrl)
 {
     if (!h || !ctrl || B <= 0 || B > h->capacity) return NMPC_EINVAL;
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpyAsync(ctrl, h->d_ctrl, sizeof(double) * (size_t)B * 6, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(ctrl, h->out_ctrl, sizeof(double) * (size_t)B * 6, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return NMPC_OK;
 }
@@ -923,7 +932,7 @@ try {
         if (rc != NMPC_OK) return rc;
         rc = nmpc_solve(h, B, NMPC_MODE_RTI, 1, 0.0);
         if (rc != NMPC_OK) return rc;
-        hipLaunchKernelGGL(nmpc_plant_kernel, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->d_ws, h->d_pv, h->d_ctrl,
+        hipLaunchKernelGGL(nmpc_plant_kernel, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->d_ws, h->d_pv, h->out_ctrl,
                            B, dt_plant, 1.0 / h->cfg.wheelbase, steering_ratio);
         HIP_TRY(hipGetLastError());
         if (trace)
@@ -952,7 +961,7 @@ void *nmpc_device_ptr(nmpc_handle *h, int which)
 {
     if (!h) return nullptr;
     switch (which) {
-        case 0: return h->d_ctrl;
+        case 0: return h->out_ctrl;
         case 1: return h->d_traj;
         case 2: return h->d_status;
         default: return nullptr;

@@ -394,3 +394,33 @@ def test_launch_order_does_not_change_results(monkeypatch):
         for va, vb in zip(a, b):
             assert np.array_equal(va, vb)
     assert len(np.unique(out["1"][0][3])) > 3   # the history the order is built from is not flat
+
+
+def test_control_records_into_a_callers_device_buffer():
+    """nmpc_set_controls_device: the records of the following solves land in the caller's device
+    buffer (what the RCCL all-gather reads), nmpc_get_controls follows it, NULL restores the
+    handle's own buffer; the records themselves are the ones of an ordinary solve."""
+    import torch
+    N, B = 40, 256
+    x0, p = sc.config2(B)
+    s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
+    s.set_x0(x0)
+    s.set_params(p)
+    s.solve(B)
+    ref = s.get_controls(B)
+    buf = torch.zeros(B * 6, dtype=torch.float64, device="cuda:0")
+    own = s.device_ptr(0)
+    s.set_controls_device(buf.data_ptr())
+    assert s.device_ptr(0) == buf.data_ptr()
+    s.reset(None, B)
+    s.solve(B)
+    s.sync()
+    got = buf.reshape(B, 6).cpu().numpy()
+    assert np.array_equal(got, ref)                       # same cold solve, same records
+    assert np.array_equal(s.get_controls(B), ref)
+    s.set_controls_device(None)
+    assert s.device_ptr(0) == own
+    s.solve(B)                                            # warm call: goes to the handle's buffer again
+    warm = s.get_controls(B)
+    assert np.array_equal(buf.reshape(B, 6).cpu().numpy(), ref) and not np.array_equal(warm, ref)
+    s.close()

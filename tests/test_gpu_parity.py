@@ -424,3 +424,26 @@ def test_control_records_into_a_callers_device_buffer():
     warm = s.get_controls(B)
     assert np.array_equal(buf.reshape(B, 6).cpu().numpy(), ref) and not np.array_equal(warm, ref)
     s.close()
+
+
+def test_horizon_sweep_on_concurrent_handles():
+    """Horizon / step-size sweeps (north_star): N and dt are per handle, handles are independent and
+    each runs on its own stream, so a sweep is one handle per (N, dt) with all solves in flight at
+    once.  Every handle must give what it gives alone (= the oracle's result)."""
+    B = 96
+    x0, p = sc.config2(B)
+    sweep = [(20, 0.35), (30, 0.35), (40, 0.35), (40, 0.2), (60, 0.25)]
+    handles = []
+    for N, dt in sweep:
+        s = capi.BatchSolver(N=N, dt=dt, capacity=B)
+        s.set_x0(x0)
+        s.set_params(p)
+        handles.append(s)
+    for s in handles:          # asynchronous: all five launches are queued before any result is read
+        s.solve(B)
+    for (N, dt), s in zip(sweep, handles):
+        g = s.get(B)
+        xo, uo, so, io = orc.rti_batch(_ocfg(N, dt), x0, p)
+        assert (g["status"] == 0).all() and (so == 0).all()
+        assert_parity(g, xo, uo, io)
+        s.close()

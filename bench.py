@@ -119,6 +119,26 @@ def cpu_baseline(N, seconds_target=12.0):
 def extras(capi, sc, hip, N):
     """Secondary measurements on one GPU (never `value`): the other BASELINE configs in short form."""
     ex = {}
+    # config 1: ONE solve (the reference's use: one vehicle, 33 ms loop budget, src/main.cpp:14), cold RTI
+    x1, p1 = sc.config2(1)
+    lat = {}
+    for n1 in (30, N):
+        s = capi.BatchSolver(N=n1, dt=0.35, capacity=1)
+        s.set_x0(x1); s.set_params(p1)
+        s.solve(1); s.sync()
+        ms = []
+        for _ in range(20):
+            s.reset(None, 1)
+            e0, e1 = hip.event(), hip.event()
+            hip.record(e0, s.stream()); s.solve(1); hip.record(e1, s.stream())
+            ms.append(hip.elapsed_ms(e0, e1))
+        t0 = time.perf_counter()
+        for _ in range(20):
+            s.reset(None, 1); s.solve(1); s.sync()
+        lat[f"N{n1}"] = {"kernel_ms": float(np.median(ms)), "call_to_sync_ms": (time.perf_counter() - t0) / 20 * 1e3}
+        s.close()
+    ex["config1_single_solve"] = dict(lat, note="one instance, cold SQP-RTI: device time of the launch and host time "
+                                                "from nmpc_reset+nmpc_solve to nmpc_sync")
     # config 3, one GPU's share: 131,072 instances in one launch (no tail effect of a small batch)
     Bl = 131072
     s = capi.BatchSolver(N=N, dt=0.35, capacity=Bl)

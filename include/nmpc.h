@@ -163,6 +163,26 @@ int nmpc_get_world_path(nmpc_handle *h, int B, double *xy);
 int nmpc_closed_loop(nmpc_handle *h, int B, int steps, double dt_plant, double steering_ratio,
                      double *world_state, const double *pitch_vref, double *trace, int32_t *n_failed);
 
+/* One SQP-RTI iteration of instances 0..B-1 (what nmpc_solve does in NMPC_MODE_RTI) WITHOUT a handle and
+ * without any allocation.  No counterpart in the reference: it exists for callers that cannot allocate
+ * device memory -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * Calls no hipMalloc / hipFree / allocating library routine; the solver's own workspace (launch order,
+ * cold-start flags, iteration history, one row of default weights and bounds) is a static device array
+ * of 344 KiB that every GPU the library runs on holds until the process ends.
+ *   cfg, device : as nmpc_create; stream : hipStream_t (NULL = default stream); asynchronous on it
+ *   B           : 1 .. NMPC_STATIC_MAX_BATCH; larger batches are rejected with NMPC_EINVAL and a message
+ *   cold != 0   : start from x_k = x0, u_k = 0 (nmpc_reset); cold == 0: warm start from d_traj as it is
+ *   inputs  (device): d_x0[B][6], d_p[B][6], d_W[B][7] or NULL, d_bnd[B][8] or NULL (NULL = cfg's values)
+ *   in/out  (device): d_traj[B][N+1][8] iterate per node X,Y,psi,v,delta,thr,u0,u1 (nmpc_device_ptr(h, 1)
+ *                     layout); d_ipm_iters int32[B] (read when cold == 0: previous counts order the launch)
+ *   outputs (device): d_ctrl[B][6] control records (nmpc_get_controls layout), d_status int32[B]
+ * Results are bit-identical to nmpc_solve on the same inputs.  All calls on one GPU share that GPU's
+ * workspace: calls that overlap on one GPU (different streams or threads) race -- serialise them. */
+#define NMPC_STATIC_MAX_BATCH 16384
+int nmpc_solve_static(const nmpc_config *cfg, int device, void *stream, int B, int cold, const double *d_x0,
+                      const double *d_p, const double *d_W, const double *d_bnd, double *d_traj, double *d_ctrl,
+                      int32_t *d_status, int32_t *d_ipm_iters);
+
 /* Device-side views for zero-copy consumers (RCCL all-gather of the control records,
  * timing with HIP events).  which: 0 control records [cap][6], 1 iterate [cap][N+1][8]
  * (X,Y,psi,v,delta,thr,u0,u1 per node), 2 status int32[cap]. */

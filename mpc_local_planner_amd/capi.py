@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NMPC_HIP_LIB") or os.path.join(_HERE, "libnmpc_hip.so")
 
 MODE_RTI, MODE_SQP = 0, 1
+STATIC_MAX_BATCH = 16384     # NMPC_STATIC_MAX_BATCH
 OK, EINVAL, EHIP, ENOMEM = 0, -1, -2, -3
 
 
@@ -35,7 +36,7 @@ class RunParams(C.Structure):
 EXPORTS = [
     "nmpc_default_config", "nmpc_config_from_file", "nmpc_create", "nmpc_destroy", "nmpc_set_x0", "nmpc_set_params",
     "nmpc_set_inputs_device", "nmpc_set_weights", "nmpc_set_bounds", "nmpc_reset", "nmpc_set_iterate",
-    "nmpc_solve",
+    "nmpc_solve", "nmpc_solve_static",
     "nmpc_sync", "nmpc_get", "nmpc_get_controls", "nmpc_device_ptr", "nmpc_stream", "nmpc_set_controls_device",
     "nmpc_capacity", "nmpc_horizon", "nmpc_last_error",
     "nmpc_set_track", "nmpc_frontend", "nmpc_get_frontend", "nmpc_get_world_path", "nmpc_closed_loop",
@@ -71,6 +72,7 @@ def lib():
     l.nmpc_reset.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int]
     l.nmpc_set_iterate.argtypes = [vp, dp, dp, C.c_int]
     l.nmpc_solve.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double]
+    l.nmpc_solve_static.argtypes = [C.POINTER(Config), C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     l.nmpc_sync.argtypes = [vp]
     l.nmpc_get.argtypes = [vp, C.c_int, dp, dp, ip, dp, ip, ip]
     l.nmpc_get_controls.argtypes = [vp, C.c_int, dp]

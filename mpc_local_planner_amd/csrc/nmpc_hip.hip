@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -277,6 +278,7 @@ struct KernelArgs {
     nmpcw::Problem pb;
     int B;
     const double *x0, *p, *W, *bnd;
+    int w_stride, bnd_stride;   // doubles between the rows of W / bnd: 7 / 8, or 0 when all instances share one row
     double *traj, *ctrl, *cost;
     int *status, *iters, *sqp_iters;
     unsigned char *reset;
@@ -292,8 +294,8 @@ __global__ void __launch_bounds__(64 * NW, 2) nmpc_solve_kernel(KernelArgs a)
     nmpcw::InstanceIO io;
     io.x0 = a.x0 + (size_t)inst * 6;
     io.p = a.p + (size_t)inst * 6;
-    io.W = a.W + (size_t)inst * 7;
-    io.bnd = a.bnd + (size_t)inst * 8;
+    io.W = a.W + (size_t)inst * a.w_stride;
+    io.bnd = a.bnd + (size_t)inst * a.bnd_stride;
     io.traj = a.traj + (size_t)inst * (a.pb.N + 1) * 8;
     io.ctrl = a.ctrl + (size_t)inst * 6;
     io.status = a.status + inst;
@@ -434,6 +436,102 @@ struct nmpc_handle {
     double *d_track = nullptr, *d_ws = nullptr, *d_pv = nullptr, *d_rot = nullptr, *d_xy = nullptr;
     int n_track = 0;
 };
+
+// Problem constants of one launch from the handle-independent configuration.
+static void fill_problem(const nmpc_config &c, int mode, int max_iter, double tol, nmpcw::Problem &pb)
+{
+    pb.N = c.N;
+    pb.dt = c.dt;
+    pb.inv_wheelbase = 1.0 / c.wheelbase;
+    pb.ipm_max_iter = c.ipm_max_iter;
+    pb.mu0 = c.ipm_mu0;
+    pb.thr0 = c.ipm_thr0;
+    pb.tau = c.ipm_tau;
+    pb.tol_mu = c.ipm_tol_mu;
+    pb.tol_lin = c.ipm_tol_lin;
+    pb.tol_comp = c.ipm_tol_comp;
+    pb.sqp_max_iter = (mode == NMPC_MODE_RTI) ? 1 : max_iter;
+    pb.sqp_tol = tol;
+}
+
+// Order kernel (optional: `hist` = iteration counts of the previous solve, `order` = its output) and
+// the solve kernel of one batch on `stream`.  Shared by nmpc_solve and nmpc_solve_static.
+static int launch_solve(KernelArgs &a, int mode, hipStream_t stream, const int *hist, int *order)
+{
+    const int B = a.B, N = a.pb.N;
+    a.order = nullptr;
+    // (beyond ~8 rounds per CU the tail is a small part of the launch and the single-workgroup sort is not free)
+    if (hist && order && B > 1 && B <= 16384) {
+        hipLaunchKernelGGL(nmpc_order_kernel, dim3(1), dim3(1024), 0, stream, hist, B, order);
+        HIP_TRY(hipGetLastError());
+        a.order = order;
+    }
+    const size_t lds_bytes = (size_t)nmpcw::lds_doubles(N) * sizeof(double);
+    // one workgroup per instance: one wave (lane = shooting node) up to N = 63, two waves beyond
+    const bool one = nmpcw::waves_per_instance(N) == 1;
+    if (mode == NMPC_MODE_RTI) {
+        if (one) hipLaunchKernelGGL((nmpc_solve_kernel<1, false>), dim3(B), dim3(64), lds_bytes, stream, a);
+        else hipLaunchKernelGGL((nmpc_solve_kernel<2, false>), dim3(B), dim3(128), lds_bytes, stream, a);
+    } else {
+        if (one) hipLaunchKernelGGL((nmpc_solve_kernel<1, true>), dim3(B), dim3(64), lds_bytes, stream, a);
+        else hipLaunchKernelGGL((nmpc_solve_kernel<2, true>), dim3(B), dim3(128), lds_bytes, stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return NMPC_OK;
+}
+
+// Horizons whose LDS image exceeds the 48 KiB a kernel gets by default need the limit raised once.
+static int raise_lds_limit(int N)
+{
+    const int lds_bytes = nmpcw::lds_doubles(N) * (int)sizeof(double);
+    if (lds_bytes <= 48 * 1024) return NMPC_OK;
+    const bool one = nmpcw::waves_per_instance(N) == 1;
+    const void *fns[2] = {one ? (const void *)nmpc_solve_kernel<1, false> : (const void *)nmpc_solve_kernel<2, false>,
+                          one ? (const void *)nmpc_solve_kernel<1, true> : (const void *)nmpc_solve_kernel<2, true>};
+    for (const void *fn : fns)
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    return NMPC_OK;
+}
+
+// ---- one entry point that allocates nothing (include/nmpc.h: nmpc_solve_static).  Everything the
+// solve needs beyond the caller's inputs and outputs -- the launch order, the iteration history it
+// is built from, the cold-start flags, per-instance SQP counters and costs, one row of default
+// weights and bounds -- lives in a file-scope device array; each GPU holds its own copy, whose
+// address is looked up once per device.
+struct StaticScratch {
+    double cost[NMPC_STATIC_MAX_BATCH];
+    double row[16];                         // W[7] | pad | bnd[8] of the configuration
+    int order[NMPC_STATIC_MAX_BATCH];
+    int hist[NMPC_STATIC_MAX_BATCH];
+    int sqp[NMPC_STATIC_MAX_BATCH];
+    unsigned char reset[NMPC_STATIC_MAX_BATCH];
+};
+static __device__ __align__(256) unsigned char scratch[sizeof(StaticScratch)];
+
+struct RowArg { double v[16]; };
+static __global__ void nmpc_static_row_kernel(double *dst, RowArg r)
+{
+    if (threadIdx.x < 16) dst[threadIdx.x] = r.v[threadIdx.x];
+}
+
+constexpr int STATIC_MAX_DEVICES = 64;
+static StaticScratch *g_static_ptr[STATIC_MAX_DEVICES];
+static bool g_static_lds_raised[STATIC_MAX_DEVICES][128];
+static std::mutex g_static_mu;
+
+// device address of `scratch` on the CURRENT device (must be `device`), looked up once per device:
+// the array's name is only a host-side stand-in, never a device address
+static int static_scratch(int device, StaticScratch **out)
+{
+    std::lock_guard<std::mutex> lk(g_static_mu);
+    if (!g_static_ptr[device]) {
+        void *p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        g_static_ptr[device] = static_cast<StaticScratch *>(p);
+    }
+    *out = g_static_ptr[device];
+    return NMPC_OK;
+}
 
 extern "C" {
 
@@ -618,18 +716,7 @@ int nmpc_create(const nmpc_config *cfg, int capacity, int device, nmpc_handle **
     }
     if (ok) ok = hip_ok(hipMemsetAsync(h->d_reset, 1, cap, h->stream), "hipMemsetAsync");
     if (ok) ok = fill_defaults(h, true, true) == NMPC_OK;
-    if (ok) {
-        const int lds_bytes = nmpcw::lds_doubles(cfg->N) * (int)sizeof(double);
-        if (lds_bytes > 48 * 1024) {
-            const bool one = nmpcw::waves_per_instance(cfg->N) == 1;
-            const void *fns[2] = {one ? (const void *)nmpc_solve_kernel<1, false> : (const void *)nmpc_solve_kernel<2, false>,
-                                  one ? (const void *)nmpc_solve_kernel<1, true> : (const void *)nmpc_solve_kernel<2, true>};
-            for (const void *fn : fns)
-                if (ok)
-                    ok = hip_ok(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes),
-                                "hipFuncSetAttribute");
-        }
-    }
+    if (ok) ok = raise_lds_limit(cfg->N) == NMPC_OK;
     if (!ok) {
         for (auto &a : allocs) if (*a.p) (void)hipFree(*a.p);
         if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -757,42 +844,73 @@ int nmpc_solve(nmpc_handle *h, int B, int mode, int max_iter, double tol)
     if (mode == NMPC_MODE_SQP && max_iter < 1) return NMPC_EINVAL;
     HIP_TRY(hipSetDevice(h->device));
     KernelArgs a;
-    a.pb.N = h->cfg.N;
-    a.pb.dt = h->cfg.dt;
-    a.pb.inv_wheelbase = 1.0 / h->cfg.wheelbase;
-    a.pb.ipm_max_iter = h->cfg.ipm_max_iter;
-    a.pb.mu0 = h->cfg.ipm_mu0;
-    a.pb.thr0 = h->cfg.ipm_thr0;
-    a.pb.tau = h->cfg.ipm_tau;
-    a.pb.tol_mu = h->cfg.ipm_tol_mu;
-    a.pb.tol_lin = h->cfg.ipm_tol_lin;
-    a.pb.tol_comp = h->cfg.ipm_tol_comp;
-    a.pb.sqp_max_iter = (mode == NMPC_MODE_RTI) ? 1 : max_iter;
-    a.pb.sqp_tol = tol;
+    fill_problem(h->cfg, mode, max_iter, tol, a.pb);
     a.B = B;
     a.x0 = h->in_x0; a.p = h->in_p; a.W = h->d_W; a.bnd = h->d_bnd;
+    a.w_stride = 7; a.bnd_stride = 8;
     a.traj = h->d_traj; a.ctrl = h->out_ctrl; a.cost = h->d_cost;
     a.status = h->d_status; a.iters = h->d_iters; a.sqp_iters = h->d_sqp;
     a.reset = h->d_reset;
-    a.order = nullptr;
-    // (beyond ~8 rounds per CU the tail is a small part of the launch and the single-workgroup sort is not free)
-    if (h->ordered && B > 1 && B <= 16384) {
-        hipLaunchKernelGGL(nmpc_order_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_iters, B, h->d_order);
+    return launch_solve(a, mode, h->stream, h->ordered ? h->d_iters : nullptr, h->d_order);
+}
+
+int nmpc_solve_static(const nmpc_config *cfg, int device, void *stream, int B, int cold, const double *d_x0,
+                      const double *d_p, const double *d_W, const double *d_bnd, double *d_traj, double *d_ctrl,
+                      int32_t *d_status, int32_t *d_ipm_iters)
+{
+    if (!cfg || !d_x0 || !d_p || !d_traj || !d_ctrl || !d_status || !d_ipm_iters || B <= 0) {
+        snprintf(g_err, sizeof(g_err), "nmpc_solve_static: null argument or B <= 0");
+        return NMPC_EINVAL;
+    }
+    if (B > NMPC_STATIC_MAX_BATCH) {
+        snprintf(g_err, sizeof(g_err), "nmpc_solve_static: B = %d exceeds NMPC_STATIC_MAX_BATCH = %d (the static "
+                 "device workspace is sized for that many instances; use nmpc_create/nmpc_solve beyond it)", B,
+                 NMPC_STATIC_MAX_BATCH);
+        return NMPC_EINVAL;
+    }
+    if (cfg->N < 1 || cfg->N > 127 || !(cfg->dt > 0.0) || !(cfg->wheelbase > 0.0)) {
+        snprintf(g_err, sizeof(g_err), "nmpc_solve_static: N in 1..127, dt > 0, wheelbase > 0");
+        return NMPC_EINVAL;
+    }
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev || device >= STATIC_MAX_DEVICES) return NMPC_EINVAL;
+    HIP_TRY(hipSetDevice(device));
+    StaticScratch *sc = nullptr;
+    int rc = static_scratch(device, &sc);
+    if (rc != NMPC_OK) return rc;
+    if (!g_static_lds_raised[device][cfg->N]) {
+        rc = raise_lds_limit(cfg->N);
+        if (rc != NMPC_OK) return rc;
+        g_static_lds_raised[device][cfg->N] = true;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // the array keeps the previous call's contents: flags are rewritten for this batch, and a cold
+    // batch has no history worth ordering by (zero = identity order)
+    HIP_TRY(hipMemsetAsync(sc->reset, cold ? 1 : 0, (size_t)B, st));
+    if (cold) HIP_TRY(hipMemsetAsync(sc->hist, 0, sizeof(int) * (size_t)B, st));
+    else HIP_TRY(hipMemcpyAsync(sc->hist, d_ipm_iters, sizeof(int) * (size_t)B, hipMemcpyDeviceToDevice, st));
+    KernelArgs a;
+    fill_problem(*cfg, NMPC_MODE_RTI, 1, 0.0, a.pb);
+    a.B = B;
+    a.x0 = d_x0; a.p = d_p;
+    a.W = d_W; a.w_stride = 7;
+    a.bnd = d_bnd; a.bnd_stride = 8;
+    if (!d_W || !d_bnd) {     // one shared row of the configuration's values
+        RowArg r;
+        memset(&r, 0, sizeof(r));
+        memcpy(r.v, cfg->W, sizeof(double) * 7);
+        r.v[8] = cfg->lbu[0]; r.v[9] = cfg->lbu[1]; r.v[10] = cfg->lbx[0]; r.v[11] = cfg->lbx[1];
+        r.v[12] = cfg->ubu[0]; r.v[13] = cfg->ubu[1]; r.v[14] = cfg->ubx[0]; r.v[15] = cfg->ubx[1];
+        hipLaunchKernelGGL(nmpc_static_row_kernel, dim3(1), dim3(64), 0, st, sc->row, r);
         HIP_TRY(hipGetLastError());
-        a.order = h->d_order;
+        if (!d_W) { a.W = sc->row; a.w_stride = 0; }
+        if (!d_bnd) { a.bnd = sc->row + 8; a.bnd_stride = 0; }
     }
-    const size_t lds_bytes = (size_t)nmpcw::lds_doubles(h->cfg.N) * sizeof(double);
-    // one workgroup per instance: one wave (lane = shooting node) up to N = 63, two waves beyond
-    const bool one = nmpcw::waves_per_instance(h->cfg.N) == 1;
-    if (mode == NMPC_MODE_RTI) {
-        if (one) hipLaunchKernelGGL((nmpc_solve_kernel<1, false>), dim3(B), dim3(64), lds_bytes, h->stream, a);
-        else hipLaunchKernelGGL((nmpc_solve_kernel<2, false>), dim3(B), dim3(128), lds_bytes, h->stream, a);
-    } else {
-        if (one) hipLaunchKernelGGL((nmpc_solve_kernel<1, true>), dim3(B), dim3(64), lds_bytes, h->stream, a);
-        else hipLaunchKernelGGL((nmpc_solve_kernel<2, true>), dim3(B), dim3(128), lds_bytes, h->stream, a);
-    }
-    HIP_TRY(hipGetLastError());
-    return NMPC_OK;
+    a.traj = d_traj; a.ctrl = d_ctrl; a.cost = sc->cost;
+    a.status = d_status; a.iters = d_ipm_iters; a.sqp_iters = sc->sqp;
+    a.reset = sc->reset;
+    return launch_solve(a, NMPC_MODE_RTI, st, sc->hist, sc->order);
 }
 
 int nmpc_sync(nmpc_handle *h)

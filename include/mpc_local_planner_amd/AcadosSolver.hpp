@@ -14,6 +14,7 @@
 
 #include <array>
 #include <chrono>
+#include <cstdint>
 #include <iostream>
 #include <sstream>
 #include <stdexcept>
@@ -27,11 +28,16 @@
 namespace mpc {
 namespace Acados {
 
-// AcadosPathTracking.h:10-47.  polyCoeffs is indexable like the reference's Eigen::Vector4d.
+// AcadosPathTracking.h:10-47.  polyCoeffs is indexable like the reference's Eigen::Vector4d, and the
+// three-argument constructor takes anything indexable [0..3] (Eigen::Vector4d, std::array, a
+// pointer ...), so src/PathTrackingSys.cpp:21 compiles unchanged with or without Eigen.
 struct PathTrackingParams : public Params {
     PathTrackingParams() = default;
-    PathTrackingParams(const std::array<double, 4> &polyCoeffs, double pitch, double vRef)
-        : polyCoeffs{polyCoeffs}, pitch{pitch}, vRef{vRef} {}
+    template <class Vec4>
+    PathTrackingParams(const Vec4 &coeffs, double pitch, double vRef)
+        : polyCoeffs{{static_cast<double>(coeffs[0]), static_cast<double>(coeffs[1]),
+                      static_cast<double>(coeffs[2]), static_cast<double>(coeffs[3])}},
+          pitch{pitch}, vRef{vRef} {}
     explicit PathTrackingParams(const std::vector<double> &v) {
         if (v.size() != size) throw std::invalid_argument("PathTrackingParams needs 6 values");
         polyCoeffs = {v[0], v[1], v[2], v[3]};
@@ -56,10 +62,19 @@ class Solver {
     Solver(const Solver &) = delete;             // the reference's class double-frees when copied
     Solver &operator=(const Solver &) = delete;
 
-    void reInit(const State &state) {            // AcadosSolver.cpp:8-13
-        freeAllocated();
-        init();
+    // AcadosSolver.cpp:8-13 frees the capsule, creates a new one and sets the cold guess.  The capsule
+    // there holds ONE solver and nothing else; the handle here also holds the track, per-instance
+    // weights / bounds, redirected control records and the warm iterates of the other capacity-1
+    // instances, so the same effect -- solver state of this instance back to the cold guess -- is
+    // reached without tearing the handle down (the kernel flags failed instances for a cold start
+    // by itself; this makes it explicit for instance 0, the one solve() drives).  The cold flag is set
+    // after the guess, so the next solve starts from ITS measurement (x_k = x0, u_k = 0): the same as
+    // setInitGuess(state) when the measurement has not moved, and not poisoned by a NaN state otherwise.
+    void reInit(const State &state) {
+        if (!handle_) init();
         setInitGuess(state);
+        const uint8_t first = 1;
+        check(nmpc_reset(handle_, &first, 1), "nmpc_reset");
     }
 
     void setInitCondition(const State &state) {  // AcadosSolver.cpp:15-26: lbx0 = ubx0 = x0
@@ -185,7 +200,7 @@ class PathTracking : public Solver {
         }
         check(nmpc_set_x0(handle_, x0.data(), B), "nmpc_set_x0");
         check(nmpc_set_params(handle_, p.data(), B), "nmpc_set_params");
-        check(nmpc_solve(handle_, B, NMPC_MODE_RTI, 1, 0.0), "nmpc_solve");
+        check(nmpc_solve(handle_, B, run_.mode, sqpMaxIter_, sqpTol_), "nmpc_solve");
         std::vector<double> x(static_cast<size_t>(B) * (N + 1) * 6), u(static_cast<size_t>(B) * N * 2);
         std::vector<int32_t> status(static_cast<size_t>(B));
         check(nmpc_get(handle_, B, x.data(), u.data(), status.data(), nullptr, nullptr, nullptr), "nmpc_get");
@@ -205,9 +220,16 @@ class PathTracking : public Solver {
     const nmpc_config &config() const { return cfg_; }
     int capacity() const { return capacity_; }
 
+    // SQP mode only (nlp_solver_type "SQP"): iteration limit and KKT tolerance; the defaults are acados'
+    // (nlp_solver_max_iter 100, nlp_solver_tol_* 1e-6), which the reference leaves untouched
+    void setSqpOptions(int maxIter, double tol) { sqpMaxIter_ = maxIter; sqpTol_ = tol; }
+    void setMode(int mode) { run_.mode = mode; }
+
    private:
     int acadosSolve() override {                                 // AcadosPathTracking.cpp:26
-        const int rc = nmpc_solve(handle_, 1, NMPC_MODE_RTI, 1, 0.0);
+        // nlp_solver_type of the parameter file selects the solver, as it selects the generated one in
+        // the reference (acados/mpcPathTracking.py:126)
+        const int rc = nmpc_solve(handle_, 1, run_.mode, sqpMaxIter_, sqpTol_);
         return rc != NMPC_OK ? rc : nmpc_sync(handle_);
     }
 
@@ -234,6 +256,8 @@ class PathTracking : public Solver {
     nmpc_run_params run_{NMPC_MODE_RTI, 30.0, 5.0, 1.0};
     int capacity_ = 1;
     int device_ = 0;
+    int sqpMaxIter_ = 100;
+    double sqpTol_ = 1e-6;
 };
 
 }  // namespace Acados

@@ -99,13 +99,17 @@ int nmpc_set_controls_device(nmpc_handle *h, double *d_ctrl);
 /* Per-instance cost weights W[B][7] / bounds bnd[B][8] = lbu0,lbu1,lbx4,lbx5,ubu0,ubu1,ubx4,ubx5
  * (the reference bakes one set into generated code, mpcPathTracking.py:103-115; the generic
  * acados setters ocp_nlp_cost_model_set / ocp_nlp_constraints_model_set are the counterpart).
- * NULL restores the handle's config values for all instances. */
+ * NULL restores the handle's config values for all instances.  Weights must be positive and finite and
+ * every lower bound below its upper bound (NMPC_EINVAL with the offending entry in nmpc_last_error()
+ * otherwise; nmpc_create checks the config the same way). */
 int nmpc_set_weights(nmpc_handle *h, const double *W, int B);
 int nmpc_set_bounds(nmpc_handle *h, const double *bnd, int B);
 
 /* Replaces Solver::setInitGuess / reInit (src/AcadosSolver.cpp:8-13,78-92): instances with
  * mask[i] != 0 (all if mask == NULL) start their next solve from x_k = x0, u_k = 0.
- * Instances whose last solve failed are reset automatically, as the reference does. */
+ * Instances whose last solve did not return status 0 (NaN, QP failure, SQP iteration limit) are reset
+ * automatically, as the reference does for every status != ACADOS_SUCCESS (src/AcadosSolver.cpp:56-59).
+ * A reset instance also forgets its iteration history (the launch order of the next solve). */
 int nmpc_reset(nmpc_handle *h, const uint8_t *mask, int B);
 
 /* Replaces the ocp_nlp_out_set "x"/"u" loop of Solver::setInitGuess (src/AcadosSolver.cpp:86-91)

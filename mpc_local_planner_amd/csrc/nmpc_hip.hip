@@ -305,20 +305,21 @@ __global__ void __launch_bounds__(64 * NW, 2) nmpc_solve_kernel(KernelArgs a)
     io.cold = a.reset[inst];
     GpuWave<NW, SQP> w{lds, lds + (a.pb.N + 1) * nmpcw::ST + nmpcw::X_SIZE};
     nmpcw::solve_instance(w, a.pb, io);
-    // failed instances restart cold next time (reference: reInit on status != 0,
-    // src/AcadosSolver.cpp:56-59); successful ones keep their iterate (warm start)
-    if (threadIdx.x == 0) a.reset[inst] = (*io.status != 0 && *io.status != 2) ? 1 : 0;
+    // instances that did not return success restart cold next time, whatever the status (NaN, QP
+    // failure, SQP iteration limit): the reference re-initialises on every status != ACADOS_SUCCESS
+    // (src/AcadosSolver.cpp:56-59); successful ones keep their iterate (warm start)
+    if (threadIdx.x == 0) a.reset[inst] = (*io.status != 0) ? 1 : 0;
 }
 
 // ---- path front-end, un-rotation and closed-loop plant: one thread per instance
 __global__ void nmpc_frontend_kernel(const double *track, int T, const double *ws, const double *pv, int B,
-                                     double *x0s, double *par, double *rot)
+                                     double *x0s, double *par, double *rot, double *ws_used)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
     double w[6], x0[6], p[6], r;
 #pragma unroll
-    for (int m = 0; m < 6; ++m) w[m] = ws[(size_t)i * 6 + m];
+    for (int m = 0; m < 6; ++m) { w[m] = ws[(size_t)i * 6 + m]; ws_used[(size_t)i * 6 + m] = w[m]; }
     nmpcf::frontend(track, T, w, pv[(size_t)i * 2], pv[(size_t)i * 2 + 1], x0, p, &r);
 #pragma unroll
     for (int m = 0; m < 6; ++m) { x0s[(size_t)i * 6 + m] = x0[m]; par[(size_t)i * 6 + m] = p[m]; }
@@ -396,10 +397,13 @@ __global__ void nmpc_fill_rows_kernel(double *dst, int rows, int width, const do
     if (i < rows * width) dst[i] = vals8[i % width];
 }
 
-__global__ void nmpc_set_reset_kernel(unsigned char *dst, const unsigned char *mask, int B)
+// cold-start flags; a reset instance also forgets its iteration history (what the launch order is
+// built from): the work of a cold solve is unrelated to that of the last warm one
+__global__ void nmpc_set_reset_kernel(unsigned char *dst, const unsigned char *mask, int B, int *iters)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) dst[i] = mask ? (mask[i] ? 1 : dst[i]) : 1;
+    if (i >= B) return;
+    if (!mask || mask[i]) { dst[i] = 1; iters[i] = 0; }
 }
 
 thread_local char g_err[256] = "";
@@ -434,6 +438,7 @@ struct nmpc_handle {
     std::vector<double> h_traj;
     // path front-end / closed loop (allocated by nmpc_set_track)
     double *d_track = nullptr, *d_ws = nullptr, *d_pv = nullptr, *d_rot = nullptr, *d_xy = nullptr;
+    double *d_wsfe = nullptr;     // the world states the last front-end pass transformed (the plant moves d_ws on)
     int n_track = 0;
 };
 
@@ -658,6 +663,40 @@ try {
     return NMPC_EINVAL;
 }
 
+// W <= 0 makes the 2x2 input Hessian singular (every solve would return status 1), lb >= ub leaves
+// no interior for the interior-point iteration: rejected where they enter
+static bool valid_weights(const double *W, int rows)
+{
+    for (int i = 0; i < rows * 7; ++i)
+        if (!(W[i] > 0.0) || !(W[i] < 1e300)) {
+            snprintf(g_err, sizeof(g_err), "weights: W[%d][%d] = %g, every weight must be positive and finite", i / 7, i % 7, W[i]);
+            return false;
+        }
+    return true;
+}
+
+static bool valid_bounds(const double *bnd, int rows)
+{
+    for (int i = 0; i < rows; ++i)
+        for (int q = 0; q < 4; ++q)
+            if (!(bnd[i * 8 + q] < bnd[i * 8 + 4 + q])) {
+                snprintf(g_err, sizeof(g_err), "bounds: row %d, bound %d: lower %g is not below upper %g", i, q,
+                         bnd[i * 8 + q], bnd[i * 8 + 4 + q]);
+                return false;
+            }
+    return true;
+}
+
+static bool valid_config(const nmpc_config *c)
+{
+    const double b[8] = {c->lbu[0], c->lbu[1], c->lbx[0], c->lbx[1], c->ubu[0], c->ubu[1], c->ubx[0], c->ubx[1]};
+    if (c->N < 1 || c->N > 127 || !(c->dt > 0.0) || !(c->wheelbase > 0.0)) {
+        snprintf(g_err, sizeof(g_err), "config: N in 1..127, dt > 0, wheelbase > 0");
+        return false;
+    }
+    return valid_weights(c->W, 1) && valid_bounds(b, 1);
+}
+
 static int fill_defaults(nmpc_handle *h, bool weights, bool bounds)
 {
     const int cap = h->capacity;
@@ -684,7 +723,7 @@ static int fill_defaults(nmpc_handle *h, bool weights, bool bounds)
 int nmpc_create(const nmpc_config *cfg, int capacity, int device, nmpc_handle **out)
 {
     if (!cfg || !out || capacity <= 0) return NMPC_EINVAL;
-    if (cfg->N < 1 || cfg->N > 127 || !(cfg->dt > 0.0) || !(cfg->wheelbase > 0.0)) return NMPC_EINVAL;
+    if (!valid_config(cfg)) return NMPC_EINVAL;
     *out = nullptr;
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -737,7 +776,7 @@ int nmpc_destroy(nmpc_handle *h)
     (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_x0, h->d_p, h->d_W, h->d_bnd, h->d_traj, h->d_ctrl, h->d_cost, h->d_tmp,
                     h->d_status, h->d_iters, h->d_sqp, h->d_order, h->d_reset, h->d_mask,
-                    h->d_track, h->d_ws, h->d_pv, h->d_rot, h->d_xy};
+                    h->d_track, h->d_ws, h->d_pv, h->d_rot, h->d_xy, h->d_wsfe};
     int rc = NMPC_OK;
     for (void *p : ptrs)
         if (p && !hip_ok(hipFree(p), "hipFree")) rc = NMPC_EHIP;
@@ -789,6 +828,7 @@ int nmpc_set_weights(nmpc_handle *h, const double *W, int B)
 {
     if (!h) return NMPC_EINVAL;
     if (!W) { HIP_TRY(hipSetDevice(h->device)); return fill_defaults(h, true, false); }
+    if (B <= 0 || B > h->capacity || !valid_weights(W, B)) return NMPC_EINVAL;
     return upload(h, h->d_W, W, B, 7);
 }
 
@@ -796,6 +836,7 @@ int nmpc_set_bounds(nmpc_handle *h, const double *bnd, int B)
 {
     if (!h) return NMPC_EINVAL;
     if (!bnd) { HIP_TRY(hipSetDevice(h->device)); return fill_defaults(h, false, true); }
+    if (B <= 0 || B > h->capacity || !valid_bounds(bnd, B)) return NMPC_EINVAL;
     return upload(h, h->d_bnd, bnd, B, 8);
 }
 
@@ -805,7 +846,7 @@ int nmpc_reset(nmpc_handle *h, const uint8_t *mask, int B)
     HIP_TRY(hipSetDevice(h->device));
     if (mask) HIP_TRY(hipMemcpyAsync(h->d_mask, mask, (size_t)B, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(nmpc_set_reset_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->d_reset,
-                       mask ? h->d_mask : nullptr, B);
+                       mask ? h->d_mask : nullptr, B, h->d_iters);
     HIP_TRY(hipGetLastError());
     if (mask) HIP_TRY(hipStreamSynchronize(h->stream));
     return NMPC_OK;
@@ -868,10 +909,7 @@ int nmpc_solve_static(const nmpc_config *cfg, int device, void *stream, int B, i
                  NMPC_STATIC_MAX_BATCH);
         return NMPC_EINVAL;
     }
-    if (cfg->N < 1 || cfg->N > 127 || !(cfg->dt > 0.0) || !(cfg->wheelbase > 0.0)) {
-        snprintf(g_err, sizeof(g_err), "nmpc_solve_static: N in 1..127, dt > 0, wheelbase > 0");
-        return NMPC_EINVAL;
-    }
+    if (!valid_config(cfg)) return NMPC_EINVAL;
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev || device >= STATIC_MAX_DEVICES) return NMPC_EINVAL;
@@ -972,14 +1010,26 @@ int nmpc_set_track(nmpc_handle *h, const double *xy, int n_points)
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     const size_t cap = (size_t)h->capacity, N1 = (size_t)h->cfg.N + 1;
-    if (h->d_track) { HIP_TRY(hipFree(h->d_track)); h->d_track = nullptr; }
-    HIP_TRY(hipMalloc((void **)&h->d_track, sizeof(double) * 2 * (size_t)n_points));
+    // all or nothing: a failed allocation leaves the handle without a track, never with a partial set
+    // of front-end buffers (the kernels of nmpc_frontend / nmpc_closed_loop take all five)
+    double *trk = nullptr;
+    HIP_TRY(hipMalloc((void **)&trk, sizeof(double) * 2 * (size_t)n_points));
     if (!h->d_ws) {
-        HIP_TRY(hipMalloc((void **)&h->d_ws, sizeof(double) * 6 * cap));
-        HIP_TRY(hipMalloc((void **)&h->d_pv, sizeof(double) * 2 * cap));
-        HIP_TRY(hipMalloc((void **)&h->d_rot, sizeof(double) * cap));
-        HIP_TRY(hipMalloc((void **)&h->d_xy, sizeof(double) * 2 * cap * N1));
+        struct { double **p; size_t bytes; } fe[] = {
+            {&h->d_ws, sizeof(double) * 6 * cap}, {&h->d_pv, sizeof(double) * 2 * cap},
+            {&h->d_rot, sizeof(double) * cap}, {&h->d_xy, sizeof(double) * 2 * cap * N1},
+            {&h->d_wsfe, sizeof(double) * 6 * cap}};
+        bool ok = true;
+        for (auto &a : fe)
+            if (ok) ok = hip_ok(hipMalloc((void **)a.p, a.bytes), "hipMalloc");
+        if (!ok) {
+            for (auto &a : fe) { if (*a.p) (void)hipFree(*a.p); *a.p = nullptr; }
+            (void)hipFree(trk);
+            return NMPC_EHIP;
+        }
     }
+    if (h->d_track) (void)hipFree(h->d_track);
+    h->d_track = trk;
     HIP_TRY(hipMemcpyAsync(h->d_track, xy, sizeof(double) * 2 * (size_t)n_points, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->n_track = n_points;
@@ -989,7 +1039,7 @@ int nmpc_set_track(nmpc_handle *h, const double *xy, int n_points)
 static int launch_frontend(nmpc_handle *h, int B)
 {
     hipLaunchKernelGGL(nmpc_frontend_kernel, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->d_track, h->n_track,
-                       h->d_ws, h->d_pv, B, h->d_x0, h->d_p, h->d_rot);
+                       h->d_ws, h->d_pv, B, h->d_x0, h->d_p, h->d_rot, h->d_wsfe);
     HIP_TRY(hipGetLastError());
     h->in_x0 = h->d_x0;
     h->in_p = h->d_p;
@@ -1024,7 +1074,8 @@ int nmpc_get_world_path(nmpc_handle *h, int B, double *xy)
     if (!h || !xy || B <= 0 || B > h->capacity || !h->d_track) return NMPC_EINVAL;
     HIP_TRY(hipSetDevice(h->device));
     const int N1 = h->cfg.N + 1;
-    hipLaunchKernelGGL(nmpc_unrotate_kernel, dim3((B * N1 + 255) / 256), dim3(256), 0, h->stream, h->d_traj, h->d_ws,
+    // with the pose the front-end transformed, not the one the plant of nmpc_closed_loop has moved on to
+    hipLaunchKernelGGL(nmpc_unrotate_kernel, dim3((B * N1 + 255) / 256), dim3(256), 0, h->stream, h->d_traj, h->d_wsfe,
                        h->d_rot, B, N1, h->d_xy);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(xy, h->d_xy, sizeof(double) * 2 * (size_t)B * N1, hipMemcpyDeviceToHost, h->stream));

@@ -51,6 +51,7 @@ int main(int argc, char **argv) {
             const double th = 2 * M_PI * i / 400.0;
             track.emplace_back(40 * cos(th), 20 * sin(th) + 20 / 1.2 * sin(3 * th));
         }
+        for (auto &pt : track) printf("track %.17g %.17g\n", pt.x, pt.y);
         mpc::PathTrackingSys sys{track, N};
         const mpc::State car{41, 0, M_PI / 2, 5, 0, 0};          // tests/testMpc.h:13
         auto r = sys.solve(car, 0.0, 5.0);
@@ -58,6 +59,41 @@ int main(int argc, char **argv) {
         for (auto &o : r.mpcHorizon) printf(" %.17g %.17g", o.x.x, o.x.y);
         printf("\n");
         if (r.mpcHorizon.size() != (size_t)N) return 5;
+        // a failed solve through solve(state, params) (NaN measurement -> status 1 -> reInit) must leave
+        // the track, and everything else the handle holds, in place: the next solve(state, pitch, vRef)
+        // works and starts from the cold guess again (src/AcadosSolver.cpp:56-59)
+        const mpc::State broken{0, 0, 0, std::nan(""), 0, 0};
+        auto rf = sys.solve(broken, params[0]);
+        printf("failed %d\n", (int)rf.success);
+        auto r2 = sys.solve(car, 0.0, 5.0);
+        printf("pts2 %d %.17g", (int)r2.success, sys.lastRotation());
+        for (auto &o : r2.mpcHorizon) printf(" %.17g %.17g", o.x.x, o.x.y);
+        printf("\n");
+    }
+    // the three-argument PathTrackingParams constructor takes anything indexable [0..3], as
+    // src/PathTrackingSys.cpp:21 passes an Eigen::Vector4d
+    {
+        struct Vec4Like { double v[4]; double operator[](int i) const { return v[i]; } };
+        const Vec4Like c{{0.5, -0.25, 0.125, -0.0625}};
+        const mpc::Acados::PathTrackingParams pp{c, 0.01, 4.5};
+        const auto v = pp.toVec();
+        if (v.size() != 6 || v[0] != 0.5 || v[1] != -0.25 || v[2] != 0.125 || v[3] != -0.0625 || v[4] != 0.01 ||
+            v[5] != 4.5)
+            return 6;
+        const double raw[4] = {1, 2, 3, 4};
+        const mpc::Acados::PathTrackingParams pq{raw, 0.0, 5.0};
+        if (pq.polyCoeffs[3] != 4.0) return 6;
+    }
+    // a parameter file with nlp_solver_type "SQP" runs full SQP (acados' defaults: 100 iterations, 1e-6),
+    // as the key selects the generated solver in the reference (acados/mpcPathTracking.py:126)
+    if (argc > 3) {
+        mpc::Acados::PathTracking sq{states[0], std::string(argv[3])};
+        auto r = sq.solve(states[0], params[0]);
+        printf("sqpfile %d %d %d", (int)r.success, sq.horizon(), sq.runParams().mode);
+        for (auto &o : r.mpcHorizon)
+            printf(" %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g", o.x.x, o.x.y, o.x.psi, o.x.vel, o.x.delta,
+                   o.x.throttle, o.u.deltaDot, o.u.throttleDot);
+        printf("\n");
     }
     // error behaviour: an impossible horizon throws from the constructor (AcadosPathTracking.cpp:42-47)
     try {

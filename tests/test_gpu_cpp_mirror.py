@@ -22,7 +22,8 @@ def test_cpp_mirror_single_and_batch(tmp_path):
     x0, p = sc.config2(B)
     inp = tmp_path / "in.txt"
     np.savetxt(inp, np.hstack([x0, p]), fmt="%.17g")
-    out = subprocess.run([EXE, str(inp), str(N)], capture_output=True, text=True, timeout=100)
+    yaml = os.path.join(ROOT, "tests", "golden", "params_sweep.yaml")       # nlp_solver_type: "SQP", N = 100
+    out = subprocess.run([EXE, str(inp), str(N), yaml], capture_output=True, text=True, timeout=100)
     assert out.returncode == 0, (out.returncode, out.stdout[-2000:], out.stderr[-2000:])
     ocfg = orc.config_like(capi.default_config(N, 0.35))
     xo, uo, so, _ = orc.rti_batch(ocfg, x0, p)
@@ -30,8 +31,13 @@ def test_cpp_mirror_single_and_batch(tmp_path):
     assert "ctor-throws ok" in lines[-1]
     nb = 0
     single = []
+    track = np.array([ln.split()[1:] for ln in lines if ln.startswith("track ")], dtype=float)
+    assert track.shape == (400, 2)
+    seen = set()
+    pts_first = None
     for ln in lines:
         t = ln.split()
+        seen.add(t[0])
         if t[0] == "batch":
             b = int(t[1])
             assert t[2] == "1" and float(t[3]) == -1.0          # success, cost = -1 (AcadosSolver.cpp:72)
@@ -44,12 +50,43 @@ def test_cpp_mirror_single_and_batch(tmp_path):
             # PathTrackingSys::solve(state, pitch, vRef): starts at the car, moves along the track
             assert t[1] == "1"
             pts = np.array(t[3:], dtype=float).reshape(N, 2)
+            pts_first = pts
             assert np.abs(pts[0] - [41.0, 0.0]).max() < 1e-9
-            assert pts[5, 1] > 3.0 and abs(pts[5, 0] - 40.0) < 3.0
+            # against the oracle's front-end + cold RTI + the un-rotation of src/PathTrackingSys.cpp:27-41
+            car = np.array([41.0, 0.0, np.pi / 2, 5.0, 0.0, 0.0])
+            rot, c = orc.calc_coeffs(track, car)
+            assert abs(float(t[2]) - rot) == 0.0
+            xs = np.array([0.0, 0.0, rot, 5.0, 0.0, 0.0])
+            pp = np.array([c[0], c[1], c[2], c[3], 0.0, 5.0])
+            xt, ut = orc.init_guess(ocfg, xs)
+            assert orc.rti(ocfg, xs, pp, xt, ut).status == 0
+            a = car[2] - rot
+            wx = xt[:N, 0] * np.cos(a) - xt[:N, 1] * np.sin(a) + car[0]
+            wy = xt[:N, 0] * np.sin(a) + xt[:N, 1] * np.cos(a) + car[1]
+            s = max(1.0, np.abs(xt).max())
+            assert np.abs(pts[:, 0] - wx).max() <= 1e-6 * s and np.abs(pts[:, 1] - wy).max() <= 1e-6 * s
+        elif t[0] == "failed":
+            assert t[1] == "0"                                   # the NaN measurement is reported as a failure
+        elif t[0] == "pts2":
+            # after the failure: track still there, instance cold again -> the very same cold solve
+            assert t[1] == "1"
+            assert np.array_equal(np.array(t[3:], dtype=float).reshape(N, 2), pts_first)
+        elif t[0] == "sqpfile":
+            assert (t[2], t[3]) == ("100", str(capi.MODE_SQP))
+            cfg_f, run_f = capi.config_from_file(yaml)
+            oc = orc.config_like(cfg_f)
+            xt, ut = orc.init_guess(oc, x0[0])
+            st = orc.sqp(oc, x0[0], p[0], xt, ut, 100, 1e-6)
+            assert int(t[1]) == int(st.status == 0)
+            if st.status == 0:
+                h = np.array(t[4:], dtype=float).reshape(100, 8)
+                s = max(1.0, np.abs(xt).max())
+                assert np.abs(h[:, :6] - xt[:100]).max() <= 1e-6 * s and np.abs(h[:, 6:] - ut).max() <= 1e-6 * s
         elif t[0] == "single":
             assert t[2] == "1"
             single.append(np.array(t[4:], dtype=float).reshape(N, 8))
     assert nb == B and len(single) == 3
+    assert {"pts", "failed", "pts2", "sqpfile"} <= seen
     # single-instance protocol: cold call, then two warm calls without shift
     x1, u1 = xo[0:1].copy(), uo[0:1].copy()
     for call in range(3):

@@ -63,7 +63,7 @@ def test_config1_single_solve_full_chain(N):
     s.close()
 
 
-def _oracle_closed_loop(t, ws, pv, N, steps, dtp, W=None):
+def _oracle_closed_loop(t, ws, pv, N, steps, dtp, W=None, ratio=1.0):
     """Python restatement of the loop of src/main.cpp:17-26 + src/RosMpc.cpp:55-95 around the oracle."""
     B = ws.shape[0]
     ws = ws.copy()
@@ -83,7 +83,7 @@ def _oracle_closed_loop(t, ws, pv, N, steps, dtp, W=None):
             if xt is None:
                 xt, ut = orc.init_guess(cfg, xs)
             st = orc.rti(cfg, xs, p, xt, ut)
-            dcmd, tcmd = xt[1, 4], xt[1, 5]
+            dcmd, tcmd = (xt[1, 4] * ratio) / ratio, xt[1, 5]    # src/RosMpc.cpp:85-90
             if st.status != 0:
                 xt = None                                   # reInit on failure (AcadosSolver.cpp:56-59)
             x = ws[i].copy(); x[4] = dcmd; x[5] = tcmd

@@ -5,12 +5,16 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 under torch.distributed.run, one rank per GPU.  A *step* is one SQP-RTI solve of one batch of
 B = 4096 independent OCP instances per GPU (BASELINE.json configs[1]: N = 40, dt = 0.35,
 randomised states / cubic path coefficients, fp64), started from the cold initial guess
-x_k = x0, u_k = 0 (src/AcadosSolver.cpp:78-92) so that every step does identical work.
-Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+x_k = x0, u_k = 0 (src/AcadosSolver.cpp:78-92).  The steps rotate over FOUR different input sets
+(all resident in HBM before the timed region; switching is a pointer swap), and a cold reset
+clears the launch-order history, so `value` does not profit from having solved the very same
+inputs before.  Rank 0 prints ONE JSON line.
 
-Extra keys: `roofline` (dominant kernel vs the fp64 vector peak; HBM view alongside),
-`cpu_baseline` (the CPU oracle on the GPU box's host cores: a restatement, NOT acados), `warm`
-(same measurement for warm-started RTI calls), `multi_gpu` (with/without the RCCL all-gather).
+Extra keys: `step_ms` (median / min / mean of the per-step kernel times), `value_no_schedule`
+(launch ordering off), `first_call` (fresh handle, one cold solve), `pcie_inclusive` (host arrays
+in, results out), `roofline` (dominant kernel vs the fp64 vector peak, with the LDS-pipe and HBM
+views alongside), `cpu_baseline` (the CPU oracle on the GPU box's host cores: a restatement, NOT
+acados), `warm` (warm-started RTI calls on correlated inputs), `multi_gpu` (with/without the gather).
 """
 import argparse
 import ctypes as C
@@ -31,16 +35,34 @@ HBM_PEAK_GBPS = 8000.0
 # cannot be read from inside this process): 2 x FETCH_SIZE (gfx950 tallies 128-B requests as 64 B;
 # the factor is calibrated for wide streaming reads only, so this is an upper bound) + WRITE_SIZE,
 # both in KiB as rocprofv3 reports them.
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1e", "pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", os.environ.get("NMPC_PMC_ROUND", "r2"), "pmc_summary.json")
+N_CU, CLOCK_HZ = 256, 2.4e9      # MI355X_MICROARCH.md chip-level parameters
+N_INPUT_SETS = 4
+
+
+def _pmc():
+    try:
+        with open(PMC_SUMMARY) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
 
 
 def pmc_traffic_bytes_per_launch():
-    """Measured HBM bytes of one B = 4096, N = 40 launch of nmpc_solve_kernel, or None."""
+    """Measured HBM bytes of one B = 4096, N = 40 launch of the solve kernel, or None."""
+    d = _pmc()
     try:
-        with open(PMC_SUMMARY) as f:
-            d = json.load(f)
         return int((2.0 * d["FETCH_SIZE"]["mean_per_launch"] + d["WRITE_SIZE"]["mean_per_launch"]) * 1024)
-    except (OSError, KeyError, ValueError):
+    except (KeyError, TypeError):
+        return None
+
+
+def pmc_lds_cycles_per_solve():
+    """LDS-array busy cycles per solve (SQ_LDS_IDX_ACTIVE / instances of the profiled launch), or None."""
+    d = _pmc()
+    try:
+        return float(d["SQ_LDS_IDX_ACTIVE"]["per_solve"])
+    except (KeyError, TypeError):
         return None
 
 
@@ -80,40 +102,71 @@ class Hip:
         return float(ms.value)
 
 
+def _fast_oracle():
+    """The oracle's source built for speed for THIS host (-O3 -march=native, OpenMP) when gcc is here,
+    else the prebuilt x86-64-v3 copy.  Timing only: results are never compared through it."""
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "oracle", "nmpc_oracle.c")
+    try:
+        out = os.path.join(tempfile.mkdtemp(prefix="nmpc_orc_"), "libnmpc_oracle_native.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-std=gnu99", "-fPIC", "-fopenmp", "-shared", "-o", out,
+                               src, "-lm"], stderr=subprocess.DEVNULL, timeout=120)
+        return C.CDLL(out), "gcc -O3 -march=native -fopenmp (built on the timing host)"
+    except Exception:
+        return C.CDLL(os.path.join(ROOT, "oracle", "libnmpc_oracle_fast.so")), "gcc -O3 -march=x86-64-v3 -fopenmp (prebuilt)"
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(N, seconds_target=12.0):
     """Time the CPU oracle (oracle/nmpc_oracle.c, 'port': a restatement, not acados/HPIPM) on a
-    bounded sample of the same workload, one instance per thread on the host cores we may use."""
-    from concurrent.futures import ThreadPoolExecutor
+    bounded sample of the same workload: one instance per OpenMP thread on the host cores this job
+    may use, and on one core beside it."""
     from oracle import oracle as orc
     from mpc_local_planner_amd import capi, scenarios as sc
-    c = capi.default_config(N, 0.35)
-    ocfg = orc.config_like(c)
-    x0, p = sc.config2(64)
-    t = time.perf_counter()
-    orc.rti_batch(ocfg, x0, p)
-    per = (time.perf_counter() - t) / 64
-    cores = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1),
-                       os.cpu_count() or 1, 16))
-    chunk = max(8, int(seconds_target / per / cores / 4))
-    nchunks = cores * 4
-    total = chunk * nchunks
-    x0, p = sc.config2(total)
-    # single core
-    n1 = max(64, int(min(total, 3.0 / per)))
-    t = time.perf_counter()
-    orc.rti_batch(ocfg, x0[:n1], p[:n1])
-    single = n1 / (time.perf_counter() - t)
+    lib, how = _fast_oracle()
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    lib.orc_rti_batch_mt.argtypes = [C.POINTER(orc.Config), C.c_int, dp, dp, dp, dp, ip, ip, C.c_int, C.c_int]
+    ocfg = orc.config_like(capi.default_config(N, 0.35))
+    nproc = os.cpu_count() or 1
+    # the job's CPU share: the GPU box exports OMP_NUM_THREADS for one GPU's share of the machine
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or nproc
+    try:
+        share = min(share, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    cores = max(1, min(share, nproc))
 
-    def work(i):
-        orc.rti_batch(ocfg, x0[i * chunk:(i + 1) * chunk], p[i * chunk:(i + 1) * chunk])
-    t = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=cores) as ex:
-        list(ex.map(work, range(nchunks)))
-    multi = total / (time.perf_counter() - t)
+    def run(n, threads):
+        x0, p = sc.config2(n)
+        xt = np.zeros((n, N + 1, 6)); ut = np.zeros((n, N, 2))
+        st = np.zeros(n, dtype=np.int32); it = np.zeros(n, dtype=np.int32)
+        t = time.perf_counter()
+        lib.orc_rti_batch_mt(C.byref(ocfg), n, x0.ctypes.data_as(dp), p.ctypes.data_as(dp), xt.ctypes.data_as(dp),
+                             ut.ctypes.data_as(dp), st.ctypes.data_as(ip), it.ctypes.data_as(ip), 1, threads)
+        dt = time.perf_counter() - t
+        assert (st == 0).mean() > 0.999, np.bincount(st)
+        return n / dt
+
+    per = 1.0 / run(128, 1)
+    single = run(max(256, int(3.0 / per)), 1)
+    total = max(1024, int(seconds_target / per * cores) // 64 * 64)
+    multi = run(total, cores)
     return {"value": multi, "unit": "solves/s", "cores": cores, "kind": "port",
-            "single_core_value": single,
-            "sample": f"{total} cold SQP-RTI solves (N={N}) of the config-2 distribution, "
-                      f"one instance per thread; CPU restatement (oracle/), not acados/HPIPM"}
+            "single_core_value": single, "nproc": nproc, "cpu_model": _cpu_model(), "build": how,
+            "sample": f"{total} cold SQP-RTI solves (N={N}) of the config-2 distribution, one instance per "
+                      f"OpenMP thread on {cores} threads (this job's share of the host's {nproc} CPUs); CPU "
+                      "restatement (oracle/, no per-solve allocation), not acados/HPIPM"}
 
 
 def extras(capi, sc, hip, N):
@@ -220,78 +273,69 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     N, B = args.horizon, args.batch
+    dev = torch.device("cuda", local_rank)
     solver = capi.BatchSolver(N=N, dt=0.35, capacity=B, device=local_rank)
     start, stop = sharding.shard_range(rank, world, world * B)   # this rank's block of the global batch
-    x0, p = sc.config2(stop - start, start=start)
-    solver.set_x0(x0)
-    solver.set_params(p)                         # inputs now resident in HBM
+    # four different global batches (cold headline) and four correlated ones (warm: consecutive control
+    # ticks see a slightly moved measurement and path, not the same one); all resident in HBM, a step
+    # only swaps the input pointers
+    host_sets = [sc.config2(stop - start, start=start + s * world * B) for s in range(N_INPUT_SETS)]
+    cold_sets = [(torch.as_tensor(x).to(dev), torch.as_tensor(p).to(dev)) for x, p in host_sets]
+    x_base, p_base = host_sets[0]
+    warm_host = [(x_base + 0.03 * s * (host_sets[s][0] - x_base), p_base + 0.03 * s * (host_sets[s][1] - p_base))
+                 for s in range(N_INPUT_SETS)]
+    warm_sets = [(torch.as_tensor(x).to(dev), torch.as_tensor(p).to(dev)) for x, p in warm_host]
+    torch.cuda.synchronize()
     hip = Hip()
     stream = solver.stream()
 
-    # control records of all ranks (RCCL all-gather over xGMI), zero-copy view of the handle's buffer
-    class _Arr:
-        def __init__(self, ptr, n):
-            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False),
-                                             "version": 2}
-    dev = torch.device("cuda", local_rank)
-    # The gather of step s overlaps the solve of step s+1: the solves write their control records
-    # alternately into two device buffers (nmpc_set_controls_device), a side stream runs the
-    # collective on the buffer a solve has just filled, and the solver's stream only waits for the
-    # collective that last read the buffer it is about to overwrite.  No host synchronisation and
-    # no copy per step.
-    solve_stream = torch.cuda.ExternalStream(int(stream), device=dev)
-    comm_stream = torch.cuda.Stream(device=dev)
-    records = [torch.zeros(B * 6, dtype=torch.float64, device=dev) for _ in range(2)]
-    gathered = [torch.empty(world * B * 6, dtype=torch.float64, device=dev) for _ in range(2)]
-    solved = [torch.cuda.Event() for _ in range(2)]
-    gather_done = [torch.cuda.Event() for _ in range(2)]
-    n_gathers = [0]
+    def use_set(slv, sets, s):
+        x, p = sets[s % N_INPUT_SETS]
+        slv.set_inputs_device(C.c_void_p(x.data_ptr()), C.c_void_p(p.data_ptr()), B)
 
-    def before_gathered_solve():
-        i = n_gathers[0] & 1
-        if n_gathers[0] >= 2:
-            solve_stream.wait_event(gather_done[i])         # the collective of two steps ago has read records[i]
-        solver.set_controls_device(records[i].data_ptr())
+    # control records of all ranks: RCCL all-gather over xGMI, overlapped with the next solve
+    # (sharding.ControlGatherPipeline: two record buffers, side stream, no host sync per step)
+    pipe = None
+    if dist_on:
+        solve_stream = torch.cuda.ExternalStream(int(stream), device=dev)
+        records = [torch.zeros(B * 6, dtype=torch.float64, device=dev) for _ in range(2)]
+        gathered = [torch.empty(world * B * 6, dtype=torch.float64, device=dev) for _ in range(2)]
+        pipe = sharding.ControlGatherPipeline(records, gathered, sharding.CudaSync(solve_stream, dev))
 
-    def enqueue_gather():
-        i = n_gathers[0] & 1
-        solved[i].record(solve_stream)
-        comm_stream.wait_event(solved[i])
-        with torch.cuda.stream(comm_stream):
-            dist.all_gather_into_tensor(gathered[i], records[i])
-            gather_done[i].record(comm_stream)
-        n_gathers[0] += 1
-
-    def barrier():
-        solver.sync()
+    def barrier(slv):
+        slv.sync()
         torch.cuda.synchronize()
         if dist_on:
             dist.barrier()
 
-    def run(steps, cold, gather, events=None):
-        for s in range(steps):
-            if cold:
-                solver.reset(None, B)
-            if gather and dist_on:
-                before_gathered_solve()
-            if events is not None:
-                hip.record(events[2 * s], stream)
-            solver.solve(B)
-            if events is not None:
-                hip.record(events[2 * s + 1], stream)
-            if gather and dist_on:
-                enqueue_gather()
+    counter = [0]
 
-    def timed(steps, cold, gather, with_events=False):
+    def run(slv, steps, cold, gather, sets, events=None):
+        for s in range(steps):
+            use_set(slv, sets, counter[0])
+            counter[0] += 1
+            if cold:
+                slv.reset(None, B)
+            if gather and pipe is not None:
+                slv.set_controls_device(pipe.records[pipe.begin_step()].data_ptr())
+            if events is not None:
+                hip.record(events[2 * s], slv.stream())
+            slv.solve(B)
+            if events is not None:
+                hip.record(events[2 * s + 1], slv.stream())
+            if gather and pipe is not None:
+                pipe.end_step()
+
+    def timed(slv, steps, cold, gather, sets, with_events=False):
         events = [hip.event() for _ in range(2 * steps)] if with_events else None
-        barrier()
+        barrier(slv)
         t0 = time.perf_counter()
-        run(steps, cold, gather, events)
-        barrier()
+        run(slv, steps, cold, gather, sets, events)
+        barrier(slv)
         dt = time.perf_counter() - t0
         kms = None
         if events:
-            kms = float(np.mean([hip.elapsed_ms(events[2 * s], events[2 * s + 1]) for s in range(steps)]))
+            kms = [hip.elapsed_ms(events[2 * s], events[2 * s + 1]) for s in range(steps)]
         if dist_on:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -299,29 +343,34 @@ def main():
         return dt, kms
 
     gather = dist_on
-    run(args.warmup, True, gather)
-    dt_main, kernel_ms = timed(args.steps, True, gather, with_events=True)
-    if dist_on:
+    run(solver, args.warmup, True, gather, cold_sets)
+    dt_main, kms_main = timed(solver, args.steps, True, gather, cold_sets, with_events=True)
+    if pipe is not None:
+        pipe.finish()
         # the last gather must hold this rank's records of the last gathered step in this rank's block
-        last = gathered[(n_gathers[0] - 1) & 1].reshape(world, B, 6)
-        if not torch.equal(last[rank], records[(n_gathers[0] - 1) & 1].reshape(B, 6)):
+        i, last = pipe.last()
+        if not torch.equal(last.reshape(world, B, 6)[rank], pipe.records[i].reshape(B, 6)):
             raise SystemExit("all-gather returned records that differ from this rank's own")
-        if not np.array_equal(solver.get_controls(B), records[(n_gathers[0] - 1) & 1].reshape(B, 6).cpu().numpy()):
+        if not np.array_equal(solver.get_controls(B), pipe.records[i].reshape(B, 6).cpu().numpy()):
             raise SystemExit("control records did not land in the caller's device buffer")
         solver.set_controls_device(None)
     g = solver.get(B)
     n_ipm_cold = float(g["ipm_iters"].mean())
     ok_cold = float((g["status"] == 0).mean())
+    kernel_ms = float(np.mean(kms_main))
 
-    # secondary measurements (not `value`): warm-started RTI; multi-GPU without the gather
-    run(2, False, False)
-    dt_warm, kernel_ms_warm = timed(args.steps, False, False, with_events=True)
+    # secondary measurements (not `value`)
+    # warm-started RTI calls on correlated inputs (closed-loop like); the launch order uses the previous tick's counts
+    use_set(solver, warm_sets, 0)
+    solver.reset(None, B)
+    run(solver, 3, False, False, warm_sets)
+    dt_warm, kms_warm = timed(solver, args.steps, False, False, warm_sets, with_events=True)
     gw = solver.get(B)
     n_ipm_warm = float(gw["ipm_iters"].mean())
     dt_nogather = None
     if dist_on:
-        run(2, True, False)
-        dt_nogather, _ = timed(args.steps, True, False)
+        run(solver, 2, True, False, cold_sets)
+        dt_nogather, _ = timed(solver, args.steps, True, False, cold_sets)
 
     total_solves = world * B * args.steps
     value = total_solves / dt_main
@@ -331,33 +380,90 @@ def main():
         "ms_per_step": 1e3 * dt_main / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"config 2: {B} path-tracking OCP instances per GPU, N={N}, dt=0.35, "
-                               "cold SQP-RTI (one QP) per step, seed 0x5EED0001",
+                               f"cold SQP-RTI (one QP) per step, steps rotate over {N_INPUT_SETS} different input "
+                               "sets resident in HBM, seed 0x5EED0001",
                    "batch_per_gpu": B, "horizon": N, "parallelism": f"dp{world} (instances sharded, "
                    "RCCL all-gather of control records)" if world > 1 else "single GPU"},
         "mean_ipm_iters": n_ipm_cold, "converged_frac": ok_cold,
+        "step_ms": {"median": float(np.median(kms_main)), "min": float(np.min(kms_main)), "mean": kernel_ms,
+                    "max": float(np.max(kms_main)), "n": len(kms_main),
+                    "note": "HIP events on the solver's stream around each step's launches"},
+        "parity": "vs CPU restatement (oracle/); acados parity unpinned",
     }
-    if kernel_ms:
-        fl = flops_per_solve(N, n_ipm_cold) * B
-        by = bytes_per_solve(N, False) * B
-        tf = fl / (kernel_ms * 1e-3) / 1e12
-        out["roofline"] = {
-            "bound": "mfma", "kernel": "nmpc_solve_kernel", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
-            "traffic": pmc_traffic_bytes_per_launch() if (B == 4096 and N == 40) else None,
-            "note": "compute roof for f64: the dense fp64 MFMA peak and the fp64 vector-FMA peak are the same "
-                    "78.6 TFLOP/s on MI355X; this kernel's flops are vector FMAs (per-instance matrices are 6x6..9x9, "
-                    "no MFMA-shaped work).  Measured binding resources are the LDS pipe and serial-recursion "
-                    "latency, see DESIGN.md section 5; the HBM view is in 'hbm'",
-            "kernel_ms": kernel_ms, "flops_per_solve": flops_per_solve(N, n_ipm_cold),
-            "peak_measured_fma64": FP64_FMA_MEASURED_TFLOPS,
-            "hbm": {"bound": "hbm", "achieved": by / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": by / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                    "bytes_per_solve": bytes_per_solve(N, False)},
-        }
+    fl = flops_per_solve(N, n_ipm_cold) * B
+    by = bytes_per_solve(N, False) * B
+    tf = fl / (kernel_ms * 1e-3) / 1e12
+    lds_cyc = pmc_lds_cycles_per_solve() if (B == 4096 and N == 40) else None
+    out["roofline"] = {
+        "bound": "valu_f64", "kernel": "nmpc_solve_kernel", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS,
+        "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
+        "traffic": pmc_traffic_bytes_per_launch() if (B == 4096 and N == 40) else None,
+        "note": "fp64 vector-FMA peak (= the dense fp64 MFMA peak, 78.6 TFLOP/s); the kernel has no MFMA-shaped work "
+                "(per-instance matrices are 6x6..9x9) and is bound by instruction issue on the serial Riccati "
+                "recursions and the LDS pipe, see 'lds' and DESIGN.md section 5; the HBM view is in 'hbm'",
+        "kernel_ms": kernel_ms, "flops_per_solve": flops_per_solve(N, n_ipm_cold),
+        "peak_measured_fma64": FP64_FMA_MEASURED_TFLOPS,
+        "hbm": {"bound": "hbm", "achieved": by / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": by / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "bytes_per_solve": bytes_per_solve(N, False)},
+    }
+    if lds_cyc:
+        ceiling = N_CU * CLOCK_HZ / lds_cyc
+        out["roofline"]["lds"] = {"bound": "lds_pipe", "lds_busy_cycles_per_solve": lds_cyc,
+                                  "ceiling_solves_per_s": ceiling, "achieved_solves_per_s": B / (kernel_ms * 1e-3),
+                                  "frac": B / (kernel_ms * 1e-3) / ceiling,
+                                  "note": "SQ_LDS_IDX_ACTIVE per solve (profiles/) -> 256 CUs x 2.4 GHz / cycles"}
     out["warm"] = {"value": total_solves / dt_warm, "ms_per_step": 1e3 * dt_warm / args.steps,
-                   "kernel_ms": kernel_ms_warm, "mean_ipm_iters": n_ipm_warm}
+                   "kernel_ms": float(np.mean(kms_warm)), "kernel_ms_median": float(np.median(kms_warm)),
+                   "mean_ipm_iters": n_ipm_warm,
+                   "note": "warm-started RTI calls; inputs move by 3 % of the spread between calls"}
     if dt_nogather:
         out["multi_gpu"] = {"with_gather": value, "without_gather": total_solves / dt_nogather}
+    if rank == 0 and world == 1:
+        # launch ordering off (a handle created under NMPC_SCHEDULE=0): same cold steps
+        os.environ["NMPC_SCHEDULE"] = "0"
+        s0 = capi.BatchSolver(N=N, dt=0.35, capacity=B, device=local_rank)
+        del os.environ["NMPC_SCHEDULE"]
+        run(s0, args.warmup, True, False, cold_sets)
+        dt0, _ = timed(s0, args.steps, True, False, cold_sets)
+        out["value_no_schedule"] = B * args.steps / dt0
+        use_set(s0, warm_sets, 0)
+        s0.reset(None, B)
+        run(s0, 3, False, False, warm_sets)
+        dtw0, _ = timed(s0, args.steps, False, False, warm_sets)
+        out["warm"]["value_no_schedule"] = B * args.steps / dtw0
+        s0.close()
+        # first call of a fresh handle: one cold solve on inputs this handle has never seen
+        fc = []
+        for rep in range(5):
+            s1 = capi.BatchSolver(N=N, dt=0.35, capacity=B, device=local_rank)
+            use_set(s1, cold_sets, rep + 1)
+            s1.sync()
+            e0, e1 = hip.event(), hip.event()
+            t0 = time.perf_counter()
+            hip.record(e0, s1.stream()); s1.solve(B); hip.record(e1, s1.stream())
+            s1.sync()
+            wall = time.perf_counter() - t0
+            fc.append((hip.elapsed_ms(e0, e1), wall * 1e3))
+            s1.close()
+        ms_dev = float(np.median([a for a, _ in fc]))
+        out["first_call"] = {"kernel_ms": ms_dev, "solves_per_s": B / (ms_dev * 1e-3),
+                             "call_to_sync_ms": float(np.median([b for _, b in fc])),
+                             "note": "fresh handle, no history, one cold solve (median of 5 handles)"}
+        # host arrays in, results out (PCIe inclusive): never `value`
+        xh, ph = host_sets[1]
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            solver.set_x0(xh); solver.set_params(ph); solver.reset(None, B); solver.solve(B); solver.get_controls(B)
+        dt_c = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            solver.set_x0(xh); solver.set_params(ph); solver.reset(None, B); solver.solve(B); solver.get(B)
+        dt_f = (time.perf_counter() - t0) / reps
+        out["pcie_inclusive"] = {"controls_only_solves_per_s": B / dt_c, "full_trajectories_solves_per_s": B / dt_f,
+                                 "note": "host x0/p in (nmpc_set_x0/params), cold solve, control records (48 B) or full "
+                                         "trajectories (2.6 KB per instance, repacked on the host) out; synchronous calls"}
     if rank == 0 and world == 1 and not args.no_extras:
         out["extras"] = extras(capi, sc, hip, N)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

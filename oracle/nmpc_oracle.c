@@ -284,12 +284,27 @@ static void riccati_solve(const orc_qp *qp, ric_ws *w, const double *Hd, const d
     }
 }
 
+/* Work areas: two per-thread blocks that grow to the largest request and are zeroed on every use
+ * (what calloc gave), so a batch of solves does not allocate per solve. */
+static __thread double *orc_ws_blk[2];
+static __thread size_t orc_ws_cap[2];
+static double *orc_ws_get(int slot, size_t n)
+{
+    if (orc_ws_cap[slot] < n) {
+        free(orc_ws_blk[slot]);
+        orc_ws_blk[slot] = (double *)malloc(n * sizeof(double));
+        orc_ws_cap[slot] = orc_ws_blk[slot] ? n : 0;
+    }
+    if (orc_ws_blk[slot]) memset(orc_ws_blk[slot], 0, n * sizeof(double));
+    return orc_ws_blk[slot];
+}
+
 int orc_qp_ipm(const orc_config *cfg, const orc_qp *qp, double *dx, double *du, double *lam,
                double *pi, int *iters, double *mu_out)
 {
     const int N = qp->N;
     const size_t nb = (size_t)N * NB;
-    double *mem = (double *)calloc((size_t)(N + 1) * NZ * 3 + nb * 13 + (size_t)N * (64 + 8 + 6 + 8 + 12 + 4 + 2), sizeof(double));
+    double *mem = orc_ws_get(0, (size_t)(N + 1) * NZ * 3 + nb * 13 + (size_t)N * (64 + 8 + 6 + 8 + 12 + 4 + 2));
     if (!mem) return 4;
     double *z = mem, *dz = z + (N + 1) * NZ, *dzc = dz + (N + 1) * NZ;
     double *tl = dzc + (N + 1) * NZ, *tu = tl + nb, *ll = tu + nb, *lu = ll + nb;
@@ -451,7 +466,7 @@ int orc_qp_ipm(const orc_config *cfg, const orc_qp *qp, double *dx, double *du, 
     }
     if (iters) *iters = it;
     if (mu_out) *mu_out = mu;
-    free(mem);
+    /* (the work area stays with the thread) */
     return status;
 }
 
@@ -470,7 +485,7 @@ typedef struct lin_ws {
 static int lin_alloc(lin_ws *w, int N)
 {
     const size_t n = (size_t)N;
-    double *m = (double *)calloc(n * (36 + 12 + 6 + 64 + 8 + 8 + 2 + 8) + (n + 1) * 12, sizeof(double));
+    double *m = orc_ws_get(1, n * (36 + 12 + 6 + 64 + 8 + 8 + 2 + 8) + (n + 1) * 12);
     if (!m) return 1;
     w->A = m; w->B = w->A + n * 36; w->b = w->B + n * 12; w->H = w->b + n * 6; w->g = w->H + n * 64;
     w->lu = w->g + n * 8; w->uu = w->lu + n * 2; w->lx = w->uu + n * 2; w->ux = w->lx + n * 2;
@@ -533,7 +548,6 @@ int orc_rti(const orc_config *c, const double *x0, const double *p, double *xtra
         st->step_inf = s;
         st->status = qs;
     }
-    free(w.A);
     return st->status;
 }
 
@@ -594,7 +608,6 @@ int orc_sqp(const orc_config *c, const double *x0, const double *p, double *xtra
         if (qs != 0) break;
     }
     st->status = status;
-    free(w.A);
     return status;
 }
 
@@ -602,6 +615,25 @@ void orc_rti_batch(const orc_config *c, int Bn, const double *x0, const double *
                    double *utraj, int *status, int *ipm_iters, int cold)
 {
     const size_t sx = (size_t)(c->N + 1) * NX, su = (size_t)c->N * NU;
+    for (int i = 0; i < Bn; ++i) {
+        orc_stats st;
+        if (cold) orc_init_guess(c, x0 + (size_t)i * NX, xtraj + i * sx, utraj + i * su);
+        orc_rti(c, x0 + (size_t)i * NX, p + (size_t)i * ORC_NP, xtraj + i * sx, utraj + i * su, &st);
+        if (status) status[i] = st.status;
+        if (ipm_iters) ipm_iters[i] = st.ipm_iters;
+    }
+}
+
+/* The same batch with one instance per OpenMP thread (bench.py's cpu_baseline leg, built with
+ * -fopenmp; without OpenMP it is the serial loop). */
+void orc_rti_batch_mt(const orc_config *c, int Bn, const double *x0, const double *p, double *xtraj,
+                      double *utraj, int *status, int *ipm_iters, int cold, int nthreads)
+{
+    const size_t sx = (size_t)(c->N + 1) * NX, su = (size_t)c->N * NU;
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads)
+#endif
     for (int i = 0; i < Bn; ++i) {
         orc_stats st;
         if (cold) orc_init_guess(c, x0 + (size_t)i * NX, xtraj + i * sx, utraj + i * su);

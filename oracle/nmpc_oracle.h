@@ -121,6 +121,9 @@ void orc_init_guess(const orc_config *cfg, const double *x0, double *xtraj, doub
    x0[B*6], p[B*6], xtraj[B*(N+1)*6], utraj[B*N*2], status[B], ipm_iters[B] */
 void orc_rti_batch(const orc_config *cfg, int B, const double *x0, const double *p, double *xtraj,
                    double *utraj, int *status, int *ipm_iters, int cold);
+/* one instance per OpenMP thread (serial without -fopenmp) */
+void orc_rti_batch_mt(const orc_config *cfg, int B, const double *x0, const double *p, double *xtraj,
+                      double *utraj, int *status, int *ipm_iters, int cold, int nthreads);
 
 /* ---- path front-end ---- */
 /* getTestTrack (utilities.cpp:59-72): returns number of points written (<= cap) */

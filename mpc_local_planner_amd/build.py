@@ -18,7 +18,8 @@ def _stale(target, sources):
 
 
 def build_hip(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, f) for f in ("nmpc_hip.hip", "nmpc_wave_solver.h", "nmpc_frontend.h", "nmpc_params_file.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("nmpc_hip.hip", "nmpc_wave_solver.h", "nmpc_quad_solver.h", "nmpc_quad_asm.inc", "nmpc_frontend.h",
+                                             "nmpc_params_file.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "nmpc.h"))
     if force or _stale(LIB, srcs):
         cmd = [HIPCC] + FLAGS + ["-o", LIB, srcs[0]]

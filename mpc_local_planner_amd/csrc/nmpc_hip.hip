@@ -12,6 +12,7 @@
 
 #define NMPC_DEV __device__ __forceinline__
 #include "nmpc_wave_solver.h"
+#include "nmpc_quad_solver.h"
 #include "nmpc_params_file.h"
 #include "nmpc_frontend.h"
 
@@ -283,6 +284,7 @@ struct KernelArgs {
     int *status, *iters, *sqp_iters;
     unsigned char *reset;
     const int *order;   // launch slot -> instance (longest expected solve first), or null
+    int *queue;         // quad kernel: ticket counter of the launch (256 B, zeroed before the launch)
 };
 
 template <int NW, bool SQP>
@@ -309,6 +311,42 @@ __global__ void __launch_bounds__(64 * NW, 2) nmpc_solve_kernel(KernelArgs a)
     // failure, SQP iteration limit): the reference re-initialises on every status != ACADOS_SUCCESS
     // (src/AcadosSolver.cpp:56-59); successful ones keep their iterate (warm start)
     if (threadIdx.x == 0) a.reset[inst] = (*io.status != 0) ? 1 : 0;
+}
+
+// ---- four instances per workgroup (nmpc_quad_solver.h): waves 0..3 are slots that do the
+// element-wise work of one instance each, the fifth wave sweeps all four (one per 16-lane DPP row).
+// Shares the vector-sweep stages, reductions and reciprocal with the one-wave policy.
+constexpr int QUAD_THREADS = 64 * nmpcq::QI;
+struct GpuQuad : GpuWave<1, false> {
+    __device__ __forceinline__ int wave() const { return (int)threadIdx.x >> 6; }
+    __device__ __forceinline__ bool sweeper() const { return ((int)threadIdx.x >> 6) == 0; }   // slot 0's wave also sweeps
+    // all five waves (the hardware barrier counts arriving waves, whichever branch they are in)
+    __device__ __forceinline__ void sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+    __device__ __forceinline__ bool uniform_flag(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
+    // next ticket of the launch-wide queue: one atomic add per wave, the same value on every lane
+    __device__ __forceinline__ int next_ticket(int *queue)
+    {
+        int t = 0;
+        if ((threadIdx.x & 63) == 0) t = atomicAdd(queue, 1);
+        return __builtin_amdgcn_readfirstlane(t);
+    }
+#include "nmpc_quad_asm.inc"
+};
+
+__global__ void __launch_bounds__(QUAD_THREADS, 2) nmpc_quad_kernel(KernelArgs a)
+{
+    extern __shared__ double lds[];
+    nmpcq::Batch bt;
+    bt.B = a.B;
+    bt.x0 = a.x0; bt.p = a.p; bt.W = a.W; bt.bnd = a.bnd;
+    bt.w_stride = a.w_stride; bt.bnd_stride = a.bnd_stride;
+    bt.traj = a.traj; bt.ctrl = a.ctrl; bt.cost = a.cost;
+    bt.status = a.status; bt.iters = a.iters; bt.sqp_iters = a.sqp_iters;
+    bt.reset = a.reset;
+    bt.order = a.order;
+    bt.queue = a.queue;
+    GpuQuad w{{lds, nullptr}};
+    nmpcq::solve_quad(w, a.pb, bt);
 }
 
 // ---- path front-end, un-rotation and closed-loop plant: one thread per instance
@@ -430,9 +468,10 @@ struct nmpc_handle {
     int device;
     hipStream_t stream;
     double *d_x0, *d_p, *d_W, *d_bnd, *d_traj, *d_ctrl, *d_cost, *d_tmp;
-    int *d_status, *d_iters, *d_sqp, *d_order;
+    int *d_status, *d_iters, *d_sqp, *d_order, *d_queue;
     unsigned char *d_reset, *d_mask;
     bool ordered;                 // launch longest-expected instances first (NMPC_SCHEDULE=0 turns it off)
+    bool quad;                    // NMPC_KERNEL=quad at creation: SQP-RTI up to N = 63 on the four-slot kernel
     const double *in_x0, *in_p;   // what the kernel reads (own buffers or caller's device buffers)
     double *out_ctrl;             // where the control records go (own buffer or the caller's device buffer)
     std::vector<double> h_traj;
@@ -459,9 +498,19 @@ static void fill_problem(const nmpc_config &c, int mode, int max_iter, double to
     pb.sqp_tol = tol;
 }
 
+// Which solve kernel.  The default is the one-instance-per-workgroup kernel (nmpc_wave_solver.h);
+// NMPC_KERNEL=quad selects the four-slots-per-workgroup kernel (nmpc_quad_solver.h) for SQP-RTI up to
+// N = 63 -- measured no faster at N = 40 (profiles/r2), kept as a tested
+// alternative.  Read when a handle is created / per call of nmpc_solve_static.
+static bool quad_kernel_requested()
+{
+    const char *e = getenv("NMPC_KERNEL");
+    return e && strcmp(e, "quad") == 0;
+}
+
 // Order kernel (optional: `hist` = iteration counts of the previous solve, `order` = its output) and
 // the solve kernel of one batch on `stream`.  Shared by nmpc_solve and nmpc_solve_static.
-static int launch_solve(KernelArgs &a, int mode, hipStream_t stream, const int *hist, int *order)
+static int launch_solve(KernelArgs &a, int mode, hipStream_t stream, const int *hist, int *order, bool quad)
 {
     const int B = a.B, N = a.pb.N;
     a.order = nullptr;
@@ -470,6 +519,21 @@ static int launch_solve(KernelArgs &a, int mode, hipStream_t stream, const int *
         hipLaunchKernelGGL(nmpc_order_kernel, dim3(1), dim3(1024), 0, stream, hist, B, order);
         HIP_TRY(hipGetLastError());
         a.order = order;
+    }
+    if (quad && mode == NMPC_MODE_RTI && nmpcw::waves_per_instance(N) == 1) {
+        // SQP-RTI up to N = 63: workgroups of four waves, each wave a slot that draws instances from a
+        // launch-wide ticket queue (nmpc_quad_solver.h); no more workgroups than can be resident at once
+        // are needed -- later ones would find the queue empty
+        if (!a.queue) return NMPC_EINVAL;
+        HIP_TRY(hipMemsetAsync(a.queue, 0, 256, stream));
+        const size_t qbytes = (size_t)nmpcq::quad_lds_doubles(N) * sizeof(double);
+        const int per_cu = (int)(160 * 1024 / qbytes) < 2 ? (int)(160 * 1024 / qbytes) : 2;   // five waves each: two per CU
+        int wgs = (B + nmpcq::QI - 1) / nmpcq::QI;
+        const int resident = 256 * (per_cu < 1 ? 1 : per_cu);
+        if (wgs > resident) wgs = resident;
+        hipLaunchKernelGGL(nmpc_quad_kernel, dim3(wgs), dim3(QUAD_THREADS), qbytes, stream, a);
+        HIP_TRY(hipGetLastError());
+        return NMPC_OK;
     }
     const size_t lds_bytes = (size_t)nmpcw::lds_doubles(N) * sizeof(double);
     // one workgroup per instance: one wave (lane = shooting node) up to N = 63, two waves beyond
@@ -488,6 +552,11 @@ static int launch_solve(KernelArgs &a, int mode, hipStream_t stream, const int *
 // Horizons whose LDS image exceeds the 48 KiB a kernel gets by default need the limit raised once.
 static int raise_lds_limit(int N)
 {
+    if (nmpcw::waves_per_instance(N) == 1) {
+        const int qbytes = nmpcq::quad_lds_doubles(N) * (int)sizeof(double);
+        if (qbytes > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)nmpc_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, qbytes));
+    }
     const int lds_bytes = nmpcw::lds_doubles(N) * (int)sizeof(double);
     if (lds_bytes <= 48 * 1024) return NMPC_OK;
     const bool one = nmpcw::waves_per_instance(N) == 1;
@@ -509,6 +578,7 @@ struct StaticScratch {
     int order[NMPC_STATIC_MAX_BATCH];
     int hist[NMPC_STATIC_MAX_BATCH];
     int sqp[NMPC_STATIC_MAX_BATCH];
+    int queue[64];                          // ticket counter of the launch (256 B)
     unsigned char reset[NMPC_STATIC_MAX_BATCH];
 };
 static __device__ __align__(256) unsigned char scratch[sizeof(StaticScratch)];
@@ -743,9 +813,11 @@ int nmpc_create(const nmpc_config *cfg, int capacity, int device, nmpc_handle **
         {(void **)&h->d_status, cap * sizeof(int)},      {(void **)&h->d_iters, cap * sizeof(int)},
         {(void **)&h->d_sqp, cap * sizeof(int)},         {(void **)&h->d_reset, cap},
         {(void **)&h->d_mask, cap},                      {(void **)&h->d_order, cap * sizeof(int)},
+        {(void **)&h->d_queue, 256},
     };
     const char *sched = getenv("NMPC_SCHEDULE");
     h->ordered = !(sched && sched[0] == '0');
+    h->quad = quad_kernel_requested();
     for (auto &a : allocs) *a.p = nullptr;
     bool ok = hip_ok(hipStreamCreate(&h->stream), "hipStreamCreate");
     for (auto &a : allocs) {
@@ -775,7 +847,7 @@ int nmpc_destroy(nmpc_handle *h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_x0, h->d_p, h->d_W, h->d_bnd, h->d_traj, h->d_ctrl, h->d_cost, h->d_tmp,
-                    h->d_status, h->d_iters, h->d_sqp, h->d_order, h->d_reset, h->d_mask,
+                    h->d_status, h->d_iters, h->d_sqp, h->d_order, h->d_queue, h->d_reset, h->d_mask,
                     h->d_track, h->d_ws, h->d_pv, h->d_rot, h->d_xy, h->d_wsfe};
     int rc = NMPC_OK;
     for (void *p : ptrs)
@@ -892,7 +964,8 @@ int nmpc_solve(nmpc_handle *h, int B, int mode, int max_iter, double tol)
     a.traj = h->d_traj; a.ctrl = h->out_ctrl; a.cost = h->d_cost;
     a.status = h->d_status; a.iters = h->d_iters; a.sqp_iters = h->d_sqp;
     a.reset = h->d_reset;
-    return launch_solve(a, mode, h->stream, h->ordered ? h->d_iters : nullptr, h->d_order);
+    a.queue = h->d_queue;
+    return launch_solve(a, mode, h->stream, h->ordered ? h->d_iters : nullptr, h->d_order, h->quad);
 }
 
 int nmpc_solve_static(const nmpc_config *cfg, int device, void *stream, int B, int cold, const double *d_x0,
@@ -948,7 +1021,8 @@ int nmpc_solve_static(const nmpc_config *cfg, int device, void *stream, int B, i
     a.traj = d_traj; a.ctrl = d_ctrl; a.cost = sc->cost;
     a.status = d_status; a.iters = d_ipm_iters; a.sqp_iters = sc->sqp;
     a.reset = sc->reset;
-    return launch_solve(a, NMPC_MODE_RTI, st, sc->hist, sc->order);
+    a.queue = sc->queue;
+    return launch_solve(a, NMPC_MODE_RTI, st, sc->hist, sc->order, quad_kernel_requested());
 }
 
 int nmpc_sync(nmpc_handle *h)

@@ -14,11 +14,12 @@
 
 #define NMPC_DEV inline
 #include "../../mpc_local_planner_amd/csrc/nmpc_wave_solver.h"
+#include "../../mpc_local_planner_amd/csrc/nmpc_quad_solver.h"
 
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int MAXT = 128;
+constexpr int MAXT = 320;
 constexpr size_t STACK = 512 * 1024;
 
 struct Barrier {
@@ -40,6 +41,10 @@ struct Sched {
     bool sqp = false;           // SQP mode (the host picks the instantiation by mode, as nmpc_solve does)
     const nmpcw::Problem *pb = nullptr;
     const nmpcw::InstanceIO *io = nullptr;
+    // four instances per workgroup (nmpc_quad_solver.h)
+    const nmpcq::Batch *batch = nullptr;
+    int itmp[MAXT / WAVE];
+    int sweeper = 0;
 };
 
 Sched *g_s = nullptr;
@@ -209,6 +214,118 @@ void thread_main(int t)
     setcontext(&g_s->main_ctx);
 }
 
+
+// Wave policy of the four-instances-per-workgroup solver: 256 threads, wave w = instance w in the
+// element-wise phases, one wave sweeps all four (row = instance).  The factor stage restates the
+// instruction list of csrc/nmpc_quad_asm.inc with the row-broadcast multiply-add as its primitive.
+struct EmuQuad : EmuWave<false> {
+    int lane() const { return tid_ & (WAVE - 1); }
+    int wave() const { return tid_ / WAVE; }
+    bool sweeper() const { return wave() == 0; }             // slot 0's wave also sweeps
+    void sync() { barrier(g_s->wg, g_s->nt, tid_); }
+    bool uniform_flag(bool b) { return b; }
+    int next_ticket(int *queue)                // one draw per wave, the same value on every lane
+    {
+        if (lane() == 0) g_s->itmp[wave()] = (*queue)++;
+        wsync();
+        const int t = g_s->itmp[wave()];
+        wsync();
+        return t;
+    }
+    double shfl_down1(double v)                // within the wave (one instance)
+    {
+        g_s->tmp[tid_] = v;
+        wsync();
+        const double r = g_s->tmp[lane() + 1 < WAVE ? tid_ + 1 : tid_];
+        wsync();
+        return r;
+    }
+    double sum(double v)
+    {
+        g_s->tmp[tid_] = v;
+        wsync();
+        double t[WAVE];
+        memcpy(t, g_s->tmp + wave() * WAVE, sizeof(t));
+        for (int o = WAVE / 2; o >= 1; o >>= 1)
+            for (int l = 0; l < WAVE; ++l)
+                if ((l & o) == 0) { const double a = t[l] + t[l | o]; t[l] = a; t[l | o] = a; }
+        wsync();
+        return t[lane()];
+    }
+    double max(double v)
+    {
+        g_s->tmp[tid_] = v;
+        wsync();
+        const double *t = g_s->tmp + wave() * WAVE;
+        double r = t[0];
+        for (int l = 1; l < WAVE; ++l) r = t[l] > r ? t[l] : r;
+        wsync();
+        return r;
+    }
+    double rowb(double src, int C)             // value of lane C of the caller's 16-lane row
+    {
+        g_s->tmp[tid_] = src;
+        wsync();
+        const double r = g_s->tmp[(tid_ & ~15) + C];
+        wsync();
+        return r;
+    }
+    double fmacd(double acc, double src, int C, double coef) { return fma(rowb(src, C), coef, acc); }
+    void fac_fetch(const double *tj, const double *bj, double (&ba)[6])
+    {
+        for (int m = 0; m < 3; ++m) { ba[m] = tj[m]; ba[3 + m] = bj[m]; }
+    }
+    template <int OFF>
+    void fac_stage(double (&P)[8], double (&H)[8], double (&ba)[6], const double *const (&ha)[8], const double *tjn,
+                   const double *bjn, double *ka, double e8)
+    {
+        for (int i = 0; i < 8; ++i) H[i] = ha[i][OFF];
+        double M[6];
+        for (int i = 0; i < 6; ++i) M[i] = P[i + 2] * e8;
+        for (int m = 0; m < 6; ++m)
+            for (int i = 0; i < 6; ++i) M[i] = fmacd(M[i], P[i + 2], m + 2, ba[m]);
+        H[2] += M[0];
+        H[3] += M[1];
+        H[0] = fmacd(H[0], ba[0], 0, M[0]); H[0] = fmacd(H[0], ba[1], 0, M[1]);
+        H[0] = fmacd(H[0], ba[2], 0, M[2]); H[0] = fmacd(H[0], ba[4], 0, M[4]);
+        H[1] = fmacd(H[1], ba[0], 1, M[0]); H[1] = fmacd(H[1], ba[1], 1, M[1]); H[1] = fmacd(H[1], ba[2], 1, M[2]);
+        H[1] = fmacd(H[1], ba[3], 1, M[3]); H[1] = fmacd(H[1], ba[5], 1, M[5]);
+        H[4] = fmacd(H[4], ba[0], 4, M[0]); H[4] = fmacd(H[4], ba[1], 4, M[1]); H[4] += M[2];
+        H[5] = fmacd(H[5], ba[0], 5, M[0]); H[5] = fmacd(H[5], ba[1], 5, M[1]); H[5] = fmacd(H[5], ba[2], 5, M[2]);
+        H[5] = fmacd(H[5], ba[3], 5, M[3]);
+        H[6] = fmacd(H[6], ba[0], 6, M[0]); H[6] = fmacd(H[6], ba[1], 6, M[1]); H[6] = fmacd(H[6], ba[2], 6, M[2]);
+        H[6] += M[4];
+        H[7] = fmacd(H[7], ba[0], 7, M[0]); H[7] = fmacd(H[7], ba[1], 7, M[1]); H[7] = fmacd(H[7], ba[2], 7, M[2]);
+        H[7] = fmacd(H[7], ba[3], 7, M[3]); H[7] += M[5];
+        for (int m = 0; m < 3; ++m) { ba[m] = tjn[m]; ba[3 + m] = bjn[m]; }
+        const double t11 = rowb(H[1], 1), t01 = rowb(H[0], 1);
+        double det = -t01 * t01;
+        det = fmacd(det, H[0], 0, t11);
+        const double y = 1.0 / det;
+        const double n00 = -t11 * y, n01 = t01 * y;
+        const double k0 = fma(n01, H[1], n00 * H[0]);
+        double k1 = n01 * H[0];
+        k1 = fmacd(k1, H[0], 0, -(y * H[1]));
+        for (int i = 0; i < 6; ++i) H[i + 2] = fmacd(H[i + 2], H[0], i + 2, k0);
+        for (int i = 0; i < 6; ++i) H[i + 2] = fmacd(H[i + 2], H[1], i + 2, k1);
+        ka[0] = k0;
+        ka[1] = k1;
+    }
+};
+
+void thread_main_quad(int t)
+{
+    EmuQuad w;
+    w.tid_ = t;
+    nmpcq::solve_quad(w, *g_s->pb, *g_s->batch);
+    g_s->done[t] = true;
+    for (int i = 1; i < g_s->nt; ++i) {
+        const int n = (t + i) % g_s->nt;
+        if (!g_s->done[n]) setcontext(&g_s->ctx[n]);
+    }
+    setcontext(&g_s->main_ctx);
+}
+
 }  // namespace
 
 extern "C" int emu_solve_batch(int N, double dt, double wheelbase, int ipm_max_iter, double mu0,
@@ -262,6 +379,66 @@ extern "C" int emu_solve_batch(int N, double dt, double wheelbase, int ipm_max_i
         }
         for (int t = 0; t < s.nt; ++t)
             if (!s.done[t]) { fprintf(stderr, "emu: thread %d did not finish\n", t); rc = 1; }
+    }
+    g_s = nullptr;
+    return rc;
+}
+
+// SQP-RTI with the four-instances-per-workgroup solver (N <= 63): same arguments; `sweeper` = the wave
+// that runs the sweeps.  The last workgroup is padded with copies of the last instance that write nothing.
+extern "C" int emu_solve_batch_quad(int N, double dt, double wheelbase, int ipm_max_iter, double mu0, double thr0,
+                                    double tau, double tol_mu, double tol_lin, double tol_comp, int B,
+                                    const double *x0, const double *p, const double *W, const double *bnd,
+                                    double *traj, double *ctrl, int *status, int *iters, int *sqp_iters,
+                                    double *cost, int cold, int sweeper)
+{
+    (void)sweeper;
+    if (N < 1 || N > 63) return 2;
+    nmpcw::Problem pb;
+    pb.N = N; pb.dt = dt; pb.inv_wheelbase = 1.0 / wheelbase;
+    pb.ipm_max_iter = ipm_max_iter; pb.mu0 = mu0; pb.thr0 = thr0; pb.tau = tau;
+    pb.tol_mu = tol_mu; pb.tol_lin = tol_lin; pb.tol_comp = tol_comp;
+    pb.sqp_max_iter = 1; pb.sqp_tol = 0.0;
+    Sched s;
+    g_s = &s;
+    s.nt = WAVE * nmpcq::QI;
+    s.stacks.resize(STACK * s.nt);
+    const size_t nl = (size_t)nmpcq::quad_lds_doubles(N);
+    std::vector<double> lds(nl + 2);
+    s.lds = lds.data() + ((reinterpret_cast<size_t>(lds.data()) & 15) ? 1 : 0);
+    s.pb = &pb;
+    int rc = 0;
+    // one workgroup whose four slots draw the whole batch from the ticket queue; a second one after it
+    // finds the queue empty and must end at once (what surplus workgroups of a launch do)
+    std::vector<unsigned char> reset((size_t)B, (unsigned char)(cold ? 1 : 0));
+    int queue = 0;
+    nmpcq::Batch bt;
+    bt.B = B; bt.x0 = x0; bt.p = p; bt.W = W; bt.bnd = bnd; bt.w_stride = 7; bt.bnd_stride = 8;
+    bt.traj = traj; bt.ctrl = ctrl; bt.cost = cost; bt.status = status; bt.iters = iters; bt.sqp_iters = sqp_iters;
+    bt.reset = reset.data(); bt.order = nullptr; bt.queue = &queue;
+    s.batch = &bt;
+    for (int wg = 0; wg < 2 && rc == 0; ++wg) {
+        for (size_t i = 0; i < nl; ++i) s.lds[i] = -1e300 * 1e10;   // poison (-inf)
+        s.wg = Barrier();
+        for (auto &wb : s.wave) wb = Barrier();
+        s.spins = 0;
+        for (int t = 0; t < s.nt; ++t) {
+            s.done[t] = false;
+            getcontext(&s.ctx[t]);
+            s.ctx[t].uc_stack.ss_sp = s.stacks.data() + STACK * t;
+            s.ctx[t].uc_stack.ss_size = STACK;
+            s.ctx[t].uc_link = nullptr;
+            makecontext(&s.ctx[t], (void (*)())thread_main_quad, 1, t);
+        }
+        swapcontext(&s.main_ctx, &s.ctx[0]);
+        if (s.deadlock) {
+            fprintf(stderr, "emu(quad): threads never met at an exchange point\n");
+            rc = 1;
+            break;
+        }
+        for (int t = 0; t < s.nt; ++t)
+            if (!s.done[t]) { fprintf(stderr, "emu(quad): thread %d did not finish\n", t); rc = 1; }
+        if (queue < B) { fprintf(stderr, "emu(quad): workgroup ended with %d of %d tickets drawn\n", queue, B); rc = 1; }
     }
     g_s = nullptr;
     return rc;

@@ -16,7 +16,8 @@ def lib():
     if _lib is None:
         csrc = os.path.join(_HERE, "..", "mpc_local_planner_amd", "csrc")
         src = [os.path.join(_HERE, "emu", "emu_wave.cpp"), os.path.join(_HERE, "emu", "emu_frontend.cpp"),
-               os.path.join(csrc, "nmpc_wave_solver.h"), os.path.join(csrc, "nmpc_frontend.h")]
+               os.path.join(csrc, "nmpc_wave_solver.h"), os.path.join(csrc, "nmpc_quad_solver.h"),
+               os.path.join(csrc, "nmpc_frontend.h")]
         if not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src):
             subprocess.check_call(["make", "-C", os.path.join(_HERE, "emu"), "-s", "-B"])
         _lib = C.CDLL(_LIB)
@@ -24,6 +25,8 @@ def lib():
         d, i = C.c_double, C.c_int
         _lib.emu_solve_batch.argtypes = [i, d, d, i, d, d, d, d, d, d, i, d, i,
                                          dp, dp, dp, dp, dp, dp, ip, ip, ip, dp, i]
+        _lib.emu_solve_batch_quad.argtypes = [i, d, d, i, d, d, d, d, d, d, i,
+                                              dp, dp, dp, dp, dp, dp, ip, ip, ip, dp, i, i]
         _lib.emu_frontend.argtypes = [dp, i, dp, dp, i, dp, dp, dp]
         _lib.emu_plant_step.argtypes = [dp, d, d, d, d, d, d]
         _lib.emu_unrotate.argtypes = [dp, d, d, d, dp]
@@ -49,10 +52,13 @@ def plant_step(ws, delta_cmd, thr_cmd, pitch, dtp, wheelbase=2.65, steering_rati
     return ws
 
 
-def solve_batch(cfg, x0, p, W=None, bnd=None, traj=None, cold=True, sqp_max_iter=0, sqp_tol=1e-6):
+def solve_batch(cfg, x0, p, W=None, bnd=None, traj=None, cold=True, sqp_max_iter=0, sqp_tol=1e-6, kernel="auto",
+                sweeper=0):
     """cfg: any config struct with the nmpc_config field names.  sqp_max_iter = 0: one SQP-RTI
-    iteration; > 0: SQP mode, at most that many iterations (KKT residuals <= sqp_tol).  Returns a
-    dict like BatchSolver.get."""
+    iteration; > 0: SQP mode, at most that many iterations (KKT residuals <= sqp_tol).  kernel: "quad"
+    (four instances per workgroup, nmpc_quad_solver.h), "wave" (one per workgroup, nmpc_wave_solver.h)
+    or "auto" = what nmpc_solve picks by default (wave; quad is opt-in, NMPC_KERNEL=quad).  Returns a dict like
+    BatchSolver.get."""
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     p = np.ascontiguousarray(p, dtype=np.float64)
     B, N = x0.shape[0], cfg.N
@@ -72,6 +78,17 @@ def solve_batch(cfg, x0, p, W=None, bnd=None, traj=None, cold=True, sqp_max_iter
     cost = np.zeros(B)
     d = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
     i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    if kernel == "auto":
+        kernel = "wave"
+    if kernel == "quad":
+        assert sqp_max_iter == 0 and N <= 63
+        rc = lib().emu_solve_batch_quad(N, cfg.dt, cfg.wheelbase, cfg.ipm_max_iter, cfg.ipm_mu0, cfg.ipm_thr0,
+                                        cfg.ipm_tau, cfg.ipm_tol_mu, cfg.ipm_tol_lin, cfg.ipm_tol_comp,
+                                        B, d(x0), d(p), d(W), d(bnd), d(traj), d(ctrl),
+                                        i(st), i(it), i(sq), d(cost), 1 if cold else 0, sweeper)
+        assert rc == 0, "emulated lanes diverged in their sync count"
+        return dict(x=traj[:, :, :6].copy(), u=traj[:, :N, 6:].copy(), traj=traj, ctrl=ctrl, status=st,
+                    ipm_iters=it, sqp_iters=sq, cost=cost)
     rc = lib().emu_solve_batch(N, cfg.dt, cfg.wheelbase, cfg.ipm_max_iter, cfg.ipm_mu0, cfg.ipm_thr0,
                                cfg.ipm_tau, cfg.ipm_tol_mu, cfg.ipm_tol_lin, cfg.ipm_tol_comp,
                                sqp_max_iter, sqp_tol, B, d(x0), d(p), d(W), d(bnd), d(traj), d(ctrl),

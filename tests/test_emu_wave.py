@@ -16,13 +16,17 @@ def _err(g, xo, uo):
     return np.maximum(np.abs(g["x"] - xo).reshape(B, -1).max(1), np.abs(g["u"] - uo).reshape(B, -1).max(1))
 
 
-@pytest.mark.parametrize("N,gen", [(40, sc.config2), (10, sc.config2), (63, sc.config2), (1, sc.config2),
-                                   (2, sc.config2), (40, sc.config4), (64, sc.config2), (100, sc.config4)])
-def test_emulated_wave_matches_oracle_cold_and_warm(N, gen):
-    B = 12 if N <= 63 else 3            # two emulated waves per instance beyond N = 63
+@pytest.mark.parametrize("N,gen,kernel", [(40, sc.config2, "quad"), (10, sc.config2, "quad"), (63, sc.config2, "quad"),
+                                          (1, sc.config2, "quad"), (2, sc.config2, "quad"), (40, sc.config4, "quad"),
+                                          (40, sc.config2, "wave"), (1, sc.config2, "wave"),
+                                          (40, sc.config4, "wave"), (64, sc.config2, "wave"), (100, sc.config4, "wave")])
+def test_emulated_wave_matches_oracle_cold_and_warm(N, gen, kernel):
+    """Both solve kernels: "quad" = four instances per workgroup (SQP-RTI up to N = 63, what nmpc_solve
+    launches there), "wave" = one instance per workgroup (SQP mode and longer horizons)."""
+    B = 6 if N <= 63 else 3             # (not a multiple of four: two slots of the workgroup run empty at the end)
     cfg = orc.default_config(N, 0.35)
     x0, p = gen(B)
-    g = emu.solve_batch(cfg, x0, p)
+    g = emu.solve_batch(cfg, x0, p, kernel=kernel)
     xo, uo, so, io = orc.rti_batch(cfg, x0, p)
     assert (g["status"] == so).all() and (so == 0).all()
     assert (np.abs(g["ipm_iters"] - io) <= 1).all()
@@ -35,14 +39,15 @@ def test_emulated_wave_matches_oracle_cold_and_warm(N, gen):
         assert np.array_equal(g["ctrl"][:, 2:4], g["x"][:, 1, 4:6])
     # warm call from the oracle's iterate (no shift)
     traj = np.zeros((B, N + 1, 8)); traj[:, :, :6] = xo; traj[:, :N, 6:] = uo
-    g2 = emu.solve_batch(cfg, x0, p, traj=traj, cold=False)
+    g2 = emu.solve_batch(cfg, x0, p, traj=traj, cold=False, kernel=kernel, sweeper=2 if kernel == "quad" else 0)
     xo2, uo2, so2, _ = orc.rti_batch(cfg, x0, p, xo.copy(), uo.copy(), cold=False)
     ok = so2 == 0
     assert (g2["status"][ok] == 0).all()
     assert _err(g2, xo2, uo2)[ok].max() <= 1e-6 * max(1.0, np.abs(xo2).max())
 
 
-def test_emulated_wave_per_instance_weights_and_bounds():
+@pytest.mark.parametrize("kernel", ["wave", "quad"])
+def test_emulated_wave_per_instance_weights_and_bounds(kernel):
     N, B = 20, 6
     cfg = orc.default_config(N, 0.35)
     x0, p = sc.config2(B)
@@ -50,7 +55,7 @@ def test_emulated_wave_per_instance_weights_and_bounds():
     W = np.array(cfg.W[:])[None, :] * rng.uniform(0.5, 2.0, size=(B, 7))
     bnd = np.tile(np.array([-80, -0.33, -0.57, -1.0, 80, 0.33, 0.57, 1.0]), (B, 1))
     bnd[:, 1] *= rng.uniform(0.5, 1.5, size=B); bnd[:, 5] = -bnd[:, 1]
-    g = emu.solve_batch(cfg, x0, p, W=W, bnd=bnd)
+    g = emu.solve_batch(cfg, x0, p, W=W, bnd=bnd, kernel=kernel)
     for i in range(B):
         oc = orc.default_config(N, 0.35)
         for m in range(7):
@@ -93,7 +98,8 @@ def test_emulated_wave_sqp_mode_iteration_limit():
         assert np.abs(g["x"][i] - xo).max() <= 1e-7 and np.abs(g["u"][i] - uo).max() <= 1e-7
 
 
-def test_emulated_wave_failure_paths_match_the_oracle():
+@pytest.mark.parametrize("kernel", ["wave", "quad"])
+def test_emulated_wave_failure_paths_match_the_oracle(kernel):
     """Status 1 (NaN in the measurement: the iterate is left as it was) and status 4 (interior-point
     iteration limit: the step is still taken, as acados returns the failed trajectory,
     src/AcadosSolver.cpp:56-59) -- same status, same iterate as the oracle; other instances of the
@@ -102,14 +108,14 @@ def test_emulated_wave_failure_paths_match_the_oracle():
     cfg = orc.default_config(N, 0.35)
     x0, p = sc.config2(B)
     x0[1, 3] = np.nan
-    g = emu.solve_batch(cfg, x0, p)
+    g = emu.solve_batch(cfg, x0, p, kernel=kernel)
     xo, uo, so, io = orc.rti_batch(cfg, x0, p)
     assert g["status"].tolist() == so.tolist() == [0, 1, 0, 0]
     ok = so == 0
     assert _err(dict(x=g["x"][ok], u=g["u"][ok]), xo[ok], uo[ok]).max() <= 1e-7
     x0, p = sc.config2(B)
     cfg3 = orc.default_config(N, 0.35, ipm_max_iter=3)
-    g = emu.solve_batch(cfg3, x0, p)
+    g = emu.solve_batch(cfg3, x0, p, kernel=kernel)
     xo, uo, so, io = orc.rti_batch(cfg3, x0, p)
     assert (g["status"] == 4).all() and (so == 4).all() and (g["ipm_iters"] == 3).all()
     assert _err(g, xo, uo).max() <= 1e-9

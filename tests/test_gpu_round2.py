@@ -204,3 +204,86 @@ def test_dpp_row_broadcast_canary():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=100)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
     assert "check: 0 bad lanes" in out.stdout
+
+
+@pytest.mark.parametrize("N", [40, 30, 10, 63, 1])
+def test_quad_kernel_matches_oracle(N, monkeypatch):
+    """NMPC_KERNEL=quad: the four-slots-per-workgroup kernel (nmpc_quad_solver.h: one wave sweeps four
+    instances, one per 16-lane DPP row, slots draw instances from a ticket queue) against the oracle:
+    cold + two warm calls, batch sizes that leave slots empty, more instances than slots, and the failure
+    statuses.  The default kernel is checked by test_gpu_parity.py."""
+    monkeypatch.setenv("NMPC_KERNEL", "quad")
+    ocfg = _ocfg(N)
+    for B in (1, 7, 1500):
+        x0, p = sc.config2(B)
+        s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
+        s.set_x0(x0)
+        s.set_params(p)
+        xo = uo = None
+        for it in range(3):
+            s.solve(B)
+            g = s.get(B)
+            xo, uo, so, io = orc.rti_batch(ocfg, x0, p, xo, uo, cold=(it == 0))
+            assert (g["status"] == 0).all() and (so == 0).all()
+            if B >= 64:
+                assert_parity(g, xo, uo, io)
+            else:
+                assert (_err(g, xo, uo) <= 1e-9 * _scale(xo, uo)).all()
+            assert (np.abs(g["ipm_iters"] - io) <= 1).all()
+            ctrl = s.get_controls(B)
+            assert np.array_equal(ctrl[:, 0:2], g["u"][:, 0, :])
+            if N >= 2:
+                assert np.array_equal(ctrl[:, 2:4], g["x"][:, 1, 4:6])
+        s.close()
+    # failure statuses: NaN measurement (1) for one instance only, interior-point iteration limit (4)
+    B = 64
+    x0, p = sc.config2(B)
+    bad = x0.copy()
+    bad[5, 3] = np.nan
+    s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
+    s.set_x0(bad)
+    s.set_params(p)
+    s.solve(B)
+    g = s.get(B)
+    assert g["status"][5] == 1 and (np.delete(g["status"], 5) == 0).all()
+    s.set_x0(x0)
+    s.solve(B)              # the failed one restarts cold, the others are warm
+    assert (s.get(B)["status"] == 0).all()
+    s.close()
+    c = capi.default_config(N, 0.35)
+    c.ipm_max_iter = 3
+    s = capi.BatchSolver(cfg=c, capacity=B)
+    s.set_x0(x0)
+    s.set_params(p)
+    s.solve(B)
+    g = s.get(B)
+    xo, uo, so, io = orc.rti_batch(orc.config_like(c), x0, p)
+    assert np.array_equal(g["status"], so) and np.array_equal(g["ipm_iters"], io)
+    assert np.abs(g["x"] - xo).max() <= 1e-9 and np.abs(g["u"] - uo).max() <= 1e-9
+    s.close()
+
+
+def test_quad_kernel_full_batch_and_weights(monkeypatch):
+    """The quad kernel on config 2 at full size with per-instance weights and bounds, against the
+    default kernel on the same inputs (both within the bar of the oracle, hence of each other)."""
+    N, B = 40, 4096
+    x0, p = sc.config2(B)
+    rng = np.random.default_rng(3)
+    W = np.array(capi.default_config(N, 0.35).W[:])[None, :] * rng.uniform(0.5, 2.0, size=(B, 7))
+    out = {}
+    for kern in ("quad", "wave"):
+        monkeypatch.setenv("NMPC_KERNEL", kern)
+        s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
+        s.set_x0(x0)
+        s.set_params(p)
+        s.set_weights(W)
+        s.solve(B)
+        s.solve(B)
+        out[kern] = s.get(B)
+        s.close()
+    a, b = out["quad"], out["wave"]
+    assert (a["status"] == 0).all() and (b["status"] == 0).all()
+    sc_ = _scale(b["x"], b["u"])
+    e = _err(a, b["x"], b["u"])
+    assert e.max() <= TOL_BAR * sc_ and (e <= 1e-9 * sc_).mean() >= 0.99
+    assert (np.abs(a["ipm_iters"] - b["ipm_iters"]) <= 1).all()

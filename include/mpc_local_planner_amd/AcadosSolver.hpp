@@ -220,6 +220,13 @@ class PathTracking : public Solver {
     const nmpc_config &config() const { return cfg_; }
     int capacity() const { return capacity_; }
 
+    // Horizon sweep inside one batch: instance b solves with horizon N[b] (1..config().N); an empty
+    // vector restores the handle's horizon for all.  MPCReturn::mpcHorizon of solveBatch keeps
+    // config().N entries, of which the first N[b] are the instance's.
+    void setHorizons(const std::vector<int32_t> &N) {
+        check(nmpc_set_horizons(handle_, N.empty() ? nullptr : N.data(), static_cast<int>(N.size())), "nmpc_set_horizons");
+    }
+
     // SQP mode only (nlp_solver_type "SQP"): iteration limit and KKT tolerance; the defaults are acados'
     // (nlp_solver_max_iter 100, nlp_solver_tol_* 1e-6), which the reference leaves untouched
     void setSqpOptions(int maxIter, double tol) { sqpMaxIter_ = maxIter; sqpTol_ = tol; }

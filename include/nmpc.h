@@ -105,6 +105,15 @@ int nmpc_set_controls_device(nmpc_handle *h, double *d_ctrl);
 int nmpc_set_weights(nmpc_handle *h, const double *W, int B);
 int nmpc_set_bounds(nmpc_handle *h, const double *bnd, int B);
 
+/* Horizon sweep inside one launch: instance i solves the OCP with horizon N[i] (1 <= N[i] <= cfg.N, the
+ * handle's horizon, which sizes the buffers); dt is the handle's.  NULL: every instance uses cfg.N again.
+ * The reference fixes N at code generation (config/mpc_params.yaml:35, acados/mpcPathTracking.py:9), the
+ * counterpart is one generated solver per N.  An instance with horizon n uses nodes 0..n of its iterate
+ * and of nmpc_get's x / u rows (later nodes are left as they are); its result is bit-identical to that of
+ * a handle created with cfg.N = n.  Changing an instance's horizon makes its old iterate meaningless:
+ * reset it (nmpc_reset).  Solved by the one-instance-per-workgroup kernel. */
+int nmpc_set_horizons(nmpc_handle *h, const int32_t *N, int B);
+
 /* Replaces Solver::setInitGuess / reInit (src/AcadosSolver.cpp:8-13,78-92): instances with
  * mask[i] != 0 (all if mask == NULL) start their next solve from x_k = x0, u_k = 0.
  * Instances whose last solve did not return status 0 (NaN, QP failure, SQP iteration limit) are reset

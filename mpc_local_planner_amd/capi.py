@@ -35,7 +35,7 @@ class RunParams(C.Structure):
 
 EXPORTS = [
     "nmpc_default_config", "nmpc_config_from_file", "nmpc_create", "nmpc_destroy", "nmpc_set_x0", "nmpc_set_params",
-    "nmpc_set_inputs_device", "nmpc_set_weights", "nmpc_set_bounds", "nmpc_reset", "nmpc_set_iterate",
+    "nmpc_set_inputs_device", "nmpc_set_weights", "nmpc_set_bounds", "nmpc_set_horizons", "nmpc_reset", "nmpc_set_iterate",
     "nmpc_solve", "nmpc_solve_static",
     "nmpc_sync", "nmpc_get", "nmpc_get_controls", "nmpc_device_ptr", "nmpc_stream", "nmpc_set_controls_device",
     "nmpc_capacity", "nmpc_horizon", "nmpc_last_error",
@@ -69,6 +69,7 @@ def lib():
     l.nmpc_set_inputs_device.argtypes = [vp, vp, vp, C.c_int]
     l.nmpc_set_weights.argtypes = [vp, dp, C.c_int]
     l.nmpc_set_bounds.argtypes = [vp, dp, C.c_int]
+    l.nmpc_set_horizons.argtypes = [vp, ip, C.c_int]
     l.nmpc_reset.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int]
     l.nmpc_set_iterate.argtypes = [vp, dp, dp, C.c_int]
     l.nmpc_solve.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double]
@@ -175,6 +176,14 @@ class BatchSolver:
         else:
             bnd = np.ascontiguousarray(bnd, dtype=np.float64).reshape(-1, 8)
             check(lib().nmpc_set_bounds(self._h, _dp(bnd), bnd.shape[0]), "nmpc_set_bounds")
+
+    def set_horizons(self, N=None):
+        """Per-instance horizons (1..cfg.N) for the following solves, or None for cfg.N everywhere."""
+        if N is None:
+            check(lib().nmpc_set_horizons(self._h, None, self.capacity), "nmpc_set_horizons")
+        else:
+            N = np.ascontiguousarray(N, dtype=np.int32)
+            check(lib().nmpc_set_horizons(self._h, _ip(N), N.shape[0]), "nmpc_set_horizons")
 
     def reset(self, mask=None, B=None):
         if mask is None:

@@ -285,6 +285,7 @@ struct KernelArgs {
     unsigned char *reset;
     const int *order;   // launch slot -> instance (longest expected solve first), or null
     int *queue;         // quad kernel: ticket counter of the launch (256 B, zeroed before the launch)
+    const int *horizons;   // per-instance horizon 1..pb.N (nmpc_set_horizons), or null: pb.N for all
 };
 
 template <int NW, bool SQP>
@@ -305,6 +306,7 @@ __global__ void __launch_bounds__(64 * NW, 2) nmpc_solve_kernel(KernelArgs a)
     io.sqp_iters = a.sqp_iters + inst;
     io.cost = a.cost + inst;
     io.cold = a.reset[inst];
+    io.N = a.horizons ? a.horizons[inst] : 0;
     GpuWave<NW, SQP> w{lds, lds + (a.pb.N + 1) * nmpcw::ST + nmpcw::X_SIZE};
     nmpcw::solve_instance(w, a.pb, io);
     // instances that did not return success restart cold next time, whatever the status (NaN, QP
@@ -469,6 +471,8 @@ struct nmpc_handle {
     hipStream_t stream;
     double *d_x0, *d_p, *d_W, *d_bnd, *d_traj, *d_ctrl, *d_cost, *d_tmp;
     int *d_status, *d_iters, *d_sqp, *d_order, *d_queue;
+    int *d_horizons = nullptr;    // per-instance horizons (nmpc_set_horizons), allocated on first use
+    bool per_instance_N = false;
     unsigned char *d_reset, *d_mask;
     bool ordered;                 // launch longest-expected instances first (NMPC_SCHEDULE=0 turns it off)
     bool quad;                    // NMPC_KERNEL=quad at creation: SQP-RTI up to N = 63 on the four-slot kernel
@@ -848,7 +852,7 @@ int nmpc_destroy(nmpc_handle *h)
     (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_x0, h->d_p, h->d_W, h->d_bnd, h->d_traj, h->d_ctrl, h->d_cost, h->d_tmp,
                     h->d_status, h->d_iters, h->d_sqp, h->d_order, h->d_queue, h->d_reset, h->d_mask,
-                    h->d_track, h->d_ws, h->d_pv, h->d_rot, h->d_xy, h->d_wsfe};
+                    h->d_track, h->d_ws, h->d_pv, h->d_rot, h->d_xy, h->d_wsfe, h->d_horizons};
     int rc = NMPC_OK;
     for (void *p : ptrs)
         if (p && !hip_ok(hipFree(p), "hipFree")) rc = NMPC_EHIP;
@@ -912,6 +916,31 @@ int nmpc_set_bounds(nmpc_handle *h, const double *bnd, int B)
     return upload(h, h->d_bnd, bnd, B, 8);
 }
 
+int nmpc_set_horizons(nmpc_handle *h, const int32_t *N, int B)
+{
+    if (!h) return NMPC_EINVAL;
+    if (!N) { h->per_instance_N = false; return NMPC_OK; }
+    if (B <= 0 || B > h->capacity) return NMPC_EINVAL;
+    for (int i = 0; i < B; ++i)
+        if (N[i] < 1 || N[i] > h->cfg.N) {
+            snprintf(g_err, sizeof(g_err), "nmpc_set_horizons: N[%d] = %d, must be in 1..%d (the handle's horizon)", i, N[i], h->cfg.N);
+            return NMPC_EINVAL;
+        }
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->d_horizons) {
+        HIP_TRY(hipMalloc((void **)&h->d_horizons, sizeof(int) * (size_t)h->capacity));
+        // instances not named keep the handle's horizon
+        std::vector<int> all;
+        try { all.assign((size_t)h->capacity, h->cfg.N); } catch (...) { return NMPC_ENOMEM; }
+        HIP_TRY(hipMemcpyAsync(h->d_horizons, all.data(), sizeof(int) * all.size(), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_horizons, N, sizeof(int) * (size_t)B, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->per_instance_N = true;
+    return NMPC_OK;
+}
+
 int nmpc_reset(nmpc_handle *h, const uint8_t *mask, int B)
 {
     if (!h || B <= 0 || B > h->capacity) return NMPC_EINVAL;
@@ -965,7 +994,9 @@ int nmpc_solve(nmpc_handle *h, int B, int mode, int max_iter, double tol)
     a.status = h->d_status; a.iters = h->d_iters; a.sqp_iters = h->d_sqp;
     a.reset = h->d_reset;
     a.queue = h->d_queue;
-    return launch_solve(a, mode, h->stream, h->ordered ? h->d_iters : nullptr, h->d_order, h->quad);
+    a.horizons = h->per_instance_N ? h->d_horizons : nullptr;
+    // (the four-slot kernel sweeps four instances in lock step: one horizon per launch)
+    return launch_solve(a, mode, h->stream, h->ordered ? h->d_iters : nullptr, h->d_order, h->quad && !h->per_instance_N);
 }
 
 int nmpc_solve_static(const nmpc_config *cfg, int device, void *stream, int B, int cold, const double *d_x0,
@@ -1022,6 +1053,7 @@ int nmpc_solve_static(const nmpc_config *cfg, int device, void *stream, int B, i
     a.status = d_status; a.iters = d_ipm_iters; a.sqp_iters = sc->sqp;
     a.reset = sc->reset;
     a.queue = sc->queue;
+    a.horizons = nullptr;
     return launch_solve(a, NMPC_MODE_RTI, st, sc->hist, sc->order, quad_kernel_requested());
 }
 

@@ -71,6 +71,7 @@ struct InstanceIO {
     int *sqp_iters;         // QPs solved
     double *cost;
     int cold;               // != 0: start from x_k = x0, u_k = 0 (AcadosSolver.cpp:78-92)
+    int N;                  // horizon of THIS instance, 1 .. Problem::N (horizon sweeps inside one launch); 0 = Problem::N
 };
 
 // ---- LDS layout, in doubles.  [pseudo-stage -1 | stage 0 .. N-1 | exchange area]
@@ -223,7 +224,9 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
 {
     const int tid = w.tid();     // thread in the workgroup = shooting node in stage layout
     const int lane = w.lane();   // lane in the wave (the sweeps run on the first wave only)
-    const int N = pb.N;
+    // the instance's own horizon: its nodes are threads 0..N, its stages the first N of the LDS image
+    // (sized by the launch for Problem::N); everything below is written in terms of this N
+    const int N = io.N > 0 ? io.N : pb.N;
     const double h = pb.dt;
     double *const ct = w.lds();                 // pseudo-stage -1 (constant tables, z_0)
     double *const stg = ct + ST;                // stage k at stg + k*ST

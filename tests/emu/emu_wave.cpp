@@ -357,7 +357,7 @@ extern "C" int emu_solve_batch(int N, double dt, double wheelbase, int ipm_max_i
         io.x0 = x0 + (size_t)b * 6; io.p = p + (size_t)b * 6; io.W = W + (size_t)b * 7;
         io.bnd = bnd + (size_t)b * 8; io.traj = traj + (size_t)b * (N + 1) * 8;
         io.ctrl = ctrl + (size_t)b * 6; io.status = status + b; io.iters = iters + b;
-        io.sqp_iters = sqp_iters + b; io.cost = cost + b; io.cold = cold;
+        io.sqp_iters = sqp_iters + b; io.cost = cost + b; io.cold = cold; io.N = 0;
         s.io = &io;
         for (size_t i = 0; i < (size_t)nmpcw::lds_doubles(N); ++i) s.lds[i] = -1e300 * 1e10;   // poison (-inf)
         s.wg = Barrier();

@@ -287,3 +287,65 @@ def test_quad_kernel_full_batch_and_weights(monkeypatch):
     e = _err(a, b["x"], b["u"])
     assert e.max() <= TOL_BAR * sc_ and (e <= 1e-9 * sc_).mean() >= 0.99
     assert (np.abs(a["ipm_iters"] - b["ipm_iters"]) <= 1).all()
+
+
+def test_horizon_sweep_inside_one_launch():
+    """nmpc_set_horizons (north_star: horizon sweeps per launch): a batch whose instances have horizons
+    20 / 30 / 40 / 64 / 100 gives, instance by instance and bit for bit, what a handle created with that
+    horizon gives -- for a cold call and a warm one, in SQP-RTI and in SQP mode -- and so the oracle's result."""
+    B, NMAX = 120, 100
+    horizons = np.array([20, 30, 40, 64, 100], dtype=np.int32)[np.arange(B) % 5]
+    x0, p = sc.config2(B)
+    s = capi.BatchSolver(N=NMAX, dt=0.35, capacity=B)
+    s.set_x0(x0)
+    s.set_params(p)
+    s.set_horizons(horizons)
+    mixed = []
+    for call in range(2):
+        s.solve(B)
+        mixed.append(s.get(B))
+    for n in np.unique(horizons):
+        sel = np.where(horizons == n)[0]
+        one = capi.BatchSolver(N=int(n), dt=0.35, capacity=len(sel))
+        one.set_x0(x0[sel])
+        one.set_params(p[sel])
+        xo = uo = None
+        for call in range(2):
+            one.solve(len(sel))
+            g = one.get(len(sel))
+            m = mixed[call]
+            assert np.array_equal(m["x"][sel][:, :n + 1], g["x"]) and np.array_equal(m["u"][sel][:, :n], g["u"])
+            assert np.array_equal(m["status"][sel], g["status"]) and np.array_equal(m["ipm_iters"][sel], g["ipm_iters"])
+            assert np.array_equal(m["cost"][sel], g["cost"])
+            assert (m["x"][sel][:, n + 1:] == 0).all()          # nodes beyond the instance's horizon are untouched
+            if call == 0:
+                xo, uo, so, io = orc.rti_batch(_ocfg(int(n)), x0[sel], p[sel])
+                assert (so == 0).all() and (g["status"] == 0).all()
+                assert (_err(g, xo, uo) <= 1e-9 * _scale(xo, uo)).all()
+        one.close()
+    # back to one horizon for all; SQP mode with mixed horizons
+    s.set_horizons(None)
+    s.reset(None, B)
+    s.solve(B)
+    full = s.get(B)
+    assert (np.abs(full["x"][:, NMAX]).max(axis=1) > 0).all()
+    s.set_horizons(horizons)
+    s.reset(None, B)
+    s.solve(B, mode=capi.MODE_SQP, max_iter=3, tol=1e-13)
+    gs = s.get(B)
+    for n in (20, 64):
+        sel = np.where(horizons == n)[0]
+        one = capi.BatchSolver(N=n, dt=0.35, capacity=len(sel))
+        one.set_x0(x0[sel])
+        one.set_params(p[sel])
+        one.solve(len(sel), mode=capi.MODE_SQP, max_iter=3, tol=1e-13)
+        g = one.get(len(sel))
+        assert np.array_equal(gs["x"][sel][:, :n + 1], g["x"]) and np.array_equal(gs["sqp_iters"][sel], g["sqp_iters"])
+        one.close()
+    # argument checks
+    l = capi.lib()
+    bad = np.array([0, 5], dtype=np.int32)
+    assert l.nmpc_set_horizons(s.handle, bad.ctypes.data_as(C.POINTER(C.c_int32)), 2) == capi.EINVAL
+    bad = np.array([NMAX + 1], dtype=np.int32)
+    assert l.nmpc_set_horizons(s.handle, bad.ctypes.data_as(C.POINTER(C.c_int32)), 1) == capi.EINVAL
+    s.close()

@@ -196,6 +196,17 @@ int nmpc_solve_static(const nmpc_config *cfg, int device, void *stream, int B, i
                       const double *d_p, const double *d_W, const double *d_bnd, double *d_traj, double *d_ctrl,
                       int32_t *d_status, int32_t *d_ipm_iters);
 
+/* Multi-GPU (one process per GPU, instances sharded by rank, no collective on the data path): all-gather
+ * of the control records of instances 0..B-1 of every rank into d_all[world][B][6] on every rank, over
+ * RCCL / xGMI, enqueued on the handle's stream behind the solve (asynchronous; nmpc_sync waits for it).
+ * nccl_comm is the caller's ncclComm_t (ncclCommInitRank with its own rank / world size); every rank
+ * must call with the same B.  RCCL is loaded on first use (dlopen of librccl.so), there is no link-time
+ * dependency.  No reference counterpart: the reference is one process, one solver
+ * (src/PathTrackingSys.cpp:58-61); this is what lets its caller hold the whole fleet's controls on
+ * every GPU.  To overlap the gather with the next solve, alternate two buffers with
+ * nmpc_set_controls_device and run the collective on a second stream. */
+int nmpc_gather_controls(nmpc_handle *h, void *nccl_comm, int B, double *d_all);
+
 /* Device-side views for zero-copy consumers (RCCL all-gather of the control records,
  * timing with HIP events).  which: 0 control records [cap][6], 1 iterate [cap][N+1][8]
  * (X,Y,psi,v,delta,thr,u0,u1 per node), 2 status int32[cap]. */

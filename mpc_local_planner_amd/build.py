@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libnmpc_hip.so")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ldl"]
 
 
 def _stale(target, sources):

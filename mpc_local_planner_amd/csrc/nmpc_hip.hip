@@ -2,6 +2,7 @@
 // path-tracking NMPC solver.  One 64-lane wavefront (= one 64-thread workgroup)
 // per OCP instance; see nmpc_wave_solver.h for the in-wave work mapping.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -1230,6 +1231,47 @@ try {
 } catch (...) {
     snprintf(g_err, sizeof(g_err), "nmpc_closed_loop: unexpected exception");
     return NMPC_EINVAL;
+}
+
+// ---- multi-GPU: all-gather of the control records over RCCL.  RCCL is bound at
+// run time (dlopen), so the library has no link-time dependency on it and single-GPU users never load it.
+typedef int (*nccl_all_gather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
+static nccl_all_gather_fn g_all_gather = nullptr;
+static std::mutex g_rccl_mu;
+
+static int bind_rccl()
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_all_gather) return NMPC_OK;
+    void *lib = nullptr;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names)
+        if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) {
+        snprintf(g_err, sizeof(g_err), "nmpc_gather_controls: cannot load librccl.so (%s)", dlerror());
+        return NMPC_EHIP;
+    }
+    g_all_gather = (nccl_all_gather_fn)dlsym(lib, "ncclAllGather");
+    if (!g_all_gather) {
+        snprintf(g_err, sizeof(g_err), "nmpc_gather_controls: ncclAllGather not found in librccl.so");
+        return NMPC_EHIP;
+    }
+    return NMPC_OK;
+}
+
+int nmpc_gather_controls(nmpc_handle *h, void *nccl_comm, int B, double *d_all)
+{
+    if (!h || !nccl_comm || !d_all || B <= 0 || B > h->capacity) return NMPC_EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    const int rc = bind_rccl();
+    if (rc != NMPC_OK) return rc;
+    const int ncclFloat64 = 8;      // rccl.h: ncclFloat64 = ncclDouble = 8
+    const int st = g_all_gather(h->out_ctrl, d_all, (size_t)B * 6, ncclFloat64, nccl_comm, h->stream);
+    if (st != 0) {
+        snprintf(g_err, sizeof(g_err), "nmpc_gather_controls: ncclAllGather returned %d", st);
+        return NMPC_EHIP;
+    }
+    return NMPC_OK;
 }
 
 void *nmpc_device_ptr(nmpc_handle *h, int which)

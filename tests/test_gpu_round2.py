@@ -349,3 +349,40 @@ def test_horizon_sweep_inside_one_launch():
     bad = np.array([NMAX + 1], dtype=np.int32)
     assert l.nmpc_set_horizons(s.handle, bad.ctypes.data_as(C.POINTER(C.c_int32)), 1) == capi.EINVAL
     s.close()
+
+
+def test_gather_controls_over_rccl_single_rank():
+    """nmpc_gather_controls through the C ABI with a real RCCL communicator.  The test box has one GPU,
+    so the communicator has one rank (ncclCommInitAll): the gathered block must equal this rank's control
+    records, for the handle's own buffer and for a caller's buffer (nmpc_set_controls_device); the
+    two-rank logic of the collective path is covered on CPU by tests/test_dist_gloo.py."""
+    import torch
+    rccl = C.CDLL("librccl.so.1")
+    comm = C.c_void_p()
+    devs = (C.c_int * 1)(0)
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, devs) == 0
+    try:
+        N, B = 40, 512
+        x0, p = sc.config2(B)
+        s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
+        s.set_x0(x0)
+        s.set_params(p)
+        out = torch.full((B * 6,), -1.0, dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        l = capi.lib()
+        s.solve(B)
+        assert l.nmpc_gather_controls(s.handle, comm, B, C.c_void_p(out.data_ptr())) == capi.OK, l.nmpc_last_error()
+        s.sync()
+        assert np.array_equal(out.cpu().numpy().reshape(B, 6), s.get_controls(B))
+        buf = torch.zeros(B * 6, dtype=torch.float64, device="cuda:0")
+        s.set_controls_device(buf.data_ptr())
+        s.solve(B)                                       # warm call into the caller's buffer
+        assert l.nmpc_gather_controls(s.handle, comm, 100, C.c_void_p(out.data_ptr())) == capi.OK
+        s.sync()
+        got = out.cpu().numpy().reshape(B, 6)
+        assert np.array_equal(got[:100], buf.cpu().numpy().reshape(B, 6)[:100])
+        assert l.nmpc_gather_controls(s.handle, None, B, C.c_void_p(out.data_ptr())) == capi.EINVAL
+        assert l.nmpc_gather_controls(s.handle, comm, B + 1, C.c_void_p(out.data_ptr())) == capi.EINVAL
+        s.close()
+    finally:
+        rccl.ncclCommDestroy(comm)

@@ -46,6 +46,12 @@ typedef struct nmpc_config {
     int ipm_max_iter;
     double ipm_mu0, ipm_thr0, ipm_tau, ipm_tol_mu, ipm_tol_lin;
     double ipm_tol_comp;  /* every slack/multiplier pair: min(t_i, lam_i) <= this at termination */
+    /* early failure: an iteration whose infeasibility scale (product of 1 - step length so far) is still
+     * above ipm_stall_lin after ipm_stall_iter iterations is given up as QP failure (status 4) instead of
+     * running to ipm_max_iter: measured on warm config-2 sequences, every QP that failed at the limit had a
+     * scale >= 0.36 at iteration 20, every QP that converged <= 0.18.  ipm_stall_iter = 0 disables it. */
+    int ipm_stall_iter;
+    double ipm_stall_lin;
 } nmpc_config;
 
 typedef struct nmpc_handle nmpc_handle;

@@ -24,7 +24,7 @@ class Config(C.Structure):
         ("lbx", C.c_double * 2), ("ubx", C.c_double * 2),
         ("ipm_max_iter", C.c_int), ("ipm_mu0", C.c_double), ("ipm_thr0", C.c_double),
         ("ipm_tau", C.c_double), ("ipm_tol_mu", C.c_double), ("ipm_tol_lin", C.c_double),
-        ("ipm_tol_comp", C.c_double),
+        ("ipm_tol_comp", C.c_double), ("ipm_stall_iter", C.c_int), ("ipm_stall_lin", C.c_double),
     ]
 
 

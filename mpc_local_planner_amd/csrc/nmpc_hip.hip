@@ -499,6 +499,8 @@ static void fill_problem(const nmpc_config &c, int mode, int max_iter, double to
     pb.tol_mu = c.ipm_tol_mu;
     pb.tol_lin = c.ipm_tol_lin;
     pb.tol_comp = c.ipm_tol_comp;
+    pb.stall_iter = c.ipm_stall_iter;
+    pb.stall_lin = c.ipm_stall_lin;
     pb.sqp_max_iter = (mode == NMPC_MODE_RTI) ? 1 : max_iter;
     pb.sqp_tol = tol;
 }
@@ -637,6 +639,8 @@ int nmpc_default_config(nmpc_config *c, int N, double dt)
     c->ipm_tol_mu = 1e-10;
     c->ipm_tol_lin = 1e-10;
     c->ipm_tol_comp = 1e-11;
+    c->ipm_stall_iter = 20;
+    c->ipm_stall_lin = 0.3;
     return NMPC_OK;
 }
 

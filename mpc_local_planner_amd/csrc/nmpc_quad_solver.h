@@ -288,6 +288,7 @@ NMPC_DEV void solve_quad(W &w, const Problem &pb, const Batch &bt)
                 if (!(mu == mu)) qp_status = 1;
                 else if (near_end && cmax <= pb.tol_comp) qp_status = 0;
                 else if (it >= pb.ipm_max_iter) qp_status = (mu <= 1e-8 && lin_scale <= 1e-8) ? 0 : 4;
+                else if (pb.stall_iter > 0 && it >= pb.stall_iter && lin_scale > pb.stall_lin) qp_status = 4;   // stalled
             }
             if (qp_status < 0) break;       // not finished: this round iterates on it
             // ---- full step (alpha = 1, no line search), write back, free the slot

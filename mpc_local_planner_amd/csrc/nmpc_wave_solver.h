@@ -55,6 +55,8 @@ struct Problem {            // uniform over the launch
     double inv_wheelbase;   // 1/L
     int ipm_max_iter;
     double mu0, thr0, tau, tol_mu, tol_lin, tol_comp;
+    int stall_iter;         // give up (status 4) when after this many iterations ... (0: never)
+    double stall_lin;       // ... the infeasibility scale is still above this
     int sqp_max_iter;       // 1 = SQP-RTI (one QP per call)
     double sqp_tol;
 };
@@ -436,6 +438,8 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
             if (near_end && cmax <= pb.tol_comp) { qp_status = 0; break; }
 #endif
             if (it >= pb.ipm_max_iter) { qp_status = (mu <= 1e-8 && lin_scale <= 1e-8) ? 0 : 4; break; }
+            // stalled: the step lengths have stayed tiny (infeasible or hopelessly started QP)
+            if (pb.stall_iter > 0 && it >= pb.stall_iter && lin_scale > pb.stall_lin) { qp_status = 4; break; }
             {
                 double G[8];
                 G[0] = R00 * z[0] + g[0];

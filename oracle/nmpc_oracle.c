@@ -39,6 +39,8 @@ void orc_default_config(orc_config *c, int N, double dt)
     c->ipm_tol_mu = 1e-10;
     c->ipm_tol_lin = 1e-10;
     c->ipm_tol_comp = 1e-11;
+    c->ipm_stall_iter = 20;
+    c->ipm_stall_lin = 0.3;
 }
 
 /* ---------------------------------------------------------------- model */
@@ -346,6 +348,8 @@ int orc_qp_ipm(const orc_config *cfg, const orc_qp *qp, double *dx, double *du, 
             cmax = fmax(cmax, fmax(fmin(tl[q], ll[q]), fmin(tu[q], lu[q])));
         if (it > 0 && mu <= cfg->ipm_tol_mu && lin_scale <= cfg->ipm_tol_lin && cmax <= cfg->ipm_tol_comp) { status = 0; break; }
         if (it >= cfg->ipm_max_iter) { status = (mu <= 1e-8 && lin_scale <= 1e-8) ? 0 : 4; break; }
+        /* stalled: the step lengths have stayed tiny (infeasible or hopelessly started QP) */
+        if (cfg->ipm_stall_iter > 0 && it >= cfg->ipm_stall_iter && lin_scale > cfg->ipm_stall_lin) { status = 4; break; }
 
         /* residuals and barrier-augmented Newton system */
         for (int k = 0; k < N; ++k) {

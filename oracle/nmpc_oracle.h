@@ -48,6 +48,8 @@ typedef struct orc_config {
     double ipm_tol_mu;
     double ipm_tol_lin;
     double ipm_tol_comp; /* max_i min(t_i, lam_i): pairwise complementarity, see orc_qp_ipm */
+    int ipm_stall_iter;  /* early failure (status 4): after this many iterations ... (0: never) */
+    double ipm_stall_lin; /* ... the infeasibility scale is still above this */
 } orc_config;
 
 /* fills cfg with the reference's defaults (N and dt given explicitly) */

@@ -333,7 +333,7 @@ extern "C" int emu_solve_batch(int N, double dt, double wheelbase, int ipm_max_i
                                int sqp_max_iter, double sqp_tol, int B, const double *x0,
                                const double *p, const double *W, const double *bnd, double *traj,
                                double *ctrl, int *status, int *iters, int *sqp_iters, double *cost,
-                               int cold)
+                               int cold, int stall_iter, double stall_lin)
 {
     // sqp_max_iter <= 0: one SQP-RTI iteration; > 0: SQP mode with that many iterations at most
     if (N < 1 || N > 127) return 2;
@@ -342,6 +342,7 @@ extern "C" int emu_solve_batch(int N, double dt, double wheelbase, int ipm_max_i
     pb.ipm_max_iter = ipm_max_iter; pb.mu0 = mu0; pb.thr0 = thr0; pb.tau = tau;
     pb.tol_mu = tol_mu; pb.tol_lin = tol_lin; pb.tol_comp = tol_comp;
     pb.sqp_max_iter = sqp_max_iter > 0 ? sqp_max_iter : 1; pb.sqp_tol = sqp_tol;
+    pb.stall_iter = stall_iter; pb.stall_lin = stall_lin;
     Sched s;
     g_s = &s;
     s.sqp = sqp_max_iter > 0;
@@ -390,7 +391,7 @@ extern "C" int emu_solve_batch_quad(int N, double dt, double wheelbase, int ipm_
                                     double tau, double tol_mu, double tol_lin, double tol_comp, int B,
                                     const double *x0, const double *p, const double *W, const double *bnd,
                                     double *traj, double *ctrl, int *status, int *iters, int *sqp_iters,
-                                    double *cost, int cold, int sweeper)
+                                    double *cost, int cold, int sweeper, int stall_iter, double stall_lin)
 {
     (void)sweeper;
     if (N < 1 || N > 63) return 2;
@@ -399,6 +400,7 @@ extern "C" int emu_solve_batch_quad(int N, double dt, double wheelbase, int ipm_
     pb.ipm_max_iter = ipm_max_iter; pb.mu0 = mu0; pb.thr0 = thr0; pb.tau = tau;
     pb.tol_mu = tol_mu; pb.tol_lin = tol_lin; pb.tol_comp = tol_comp;
     pb.sqp_max_iter = 1; pb.sqp_tol = 0.0;
+    pb.stall_iter = stall_iter; pb.stall_lin = stall_lin;
     Sched s;
     g_s = &s;
     s.nt = WAVE * nmpcq::QI;

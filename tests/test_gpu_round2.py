@@ -386,3 +386,41 @@ def test_gather_controls_over_rccl_single_rank():
         s.close()
     finally:
         rccl.ncclCommDestroy(comm)
+
+
+def test_stalled_interior_point_iterations_fail_early():
+    """A QP on which the interior-point iteration makes no headway (infeasibility scale still above
+    ipm_stall_lin after ipm_stall_iter iterations) is reported as QP failure (status 4) at that point, on
+    the kernel as on the oracle, instead of holding a launch up until ipm_max_iter.  Found on a warm
+    sequence of config 2 (a few instances per 4096 and call); with the rule switched off the same
+    instances run to the limit and fail there."""
+    N, B = 40, 4096
+    host = [sc.config2(B, start=s * B) for s in range(2)]
+    x1 = host[0][0] + 0.03 * (host[1][0] - host[0][0])
+    p1 = host[0][1] + 0.03 * (host[1][1] - host[0][1])
+    out = {}
+    for stall in (20, 0):
+        c = capi.default_config(N, 0.35)
+        c.ipm_stall_iter = stall
+        s = capi.BatchSolver(cfg=c, capacity=B)
+        s.set_x0(host[0][0]); s.set_params(host[0][1])
+        s.solve(B)
+        s.set_x0(x1); s.set_params(p1)
+        s.solve(B)                                  # warm call on moved inputs
+        g = s.get(B)
+        oc = orc.config_like(c)
+        xo, uo, _, _ = orc.rti_batch(oc, host[0][0], host[0][1])
+        xo, uo, so, io = orc.rti_batch(oc, x1, p1, xo, uo, cold=False)
+        assert np.array_equal(g["status"], so)
+        assert (np.abs(g["ipm_iters"] - io) <= 1).all()
+        ok = so == 0
+        assert_parity(g, xo, uo, io, ok=ok)
+        out[stall] = (g["status"].copy(), g["ipm_iters"].copy())
+        s.close()
+    st_on, it_on = out[20]
+    st_off, it_off = out[0]
+    failed = st_off == 4
+    assert failed.sum() >= 1 and (it_off[failed] == 50).all()
+    assert np.array_equal(st_on == 4, failed)                  # the same instances fail, ...
+    assert (it_on[failed] == 20).all()                         # ... thirty iterations earlier
+    assert np.array_equal(it_on[~failed], it_off[~failed])     # nothing else changes

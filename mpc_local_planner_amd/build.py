@@ -7,7 +7,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libnmpc_hip.so")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ldl"]
+# -disable-machine-licm: the solve kernels sit at the 256-VGPR limit, and hoisting the materialisation
+# of fp64 literals (integrator / atan polynomials) out of the SQP and slot loops only turns them into
+# spills: with it the SQP kernels drop from 372 to 72 B of scratch per lane, the quad kernel from 344 to
+# 132 B (+6 % throughput), the SQP-RTI wave kernels use 239 / 250 VGPRs and none (measured: DESIGN.md)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ldl", "-mllvm", "-disable-machine-licm"]
 
 
 def _stale(target, sources):

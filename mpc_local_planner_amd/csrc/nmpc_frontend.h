@@ -80,9 +80,12 @@ NMPC_DEV double fit_rotation(const double *xy, int start, int end, double sx, do
     for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int c = 0; c < 5; ++c) { F.f[s][c] = 0.0; F.R[s][c] = 0.0; }
-    int steps = n < 4 ? n : 4;
-#pragma unroll 1
-    for (int j = 0; j < steps; ++j) {
+    const int steps = n < 4 ? n : 4;
+    // the four elimination steps are written out (full unroll): every index into F is then a
+    // compile-time constant and F lives in registers -- indexed by a loop variable it went to scratch
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j >= steps) break;
         // pass 1: column norm below and including the pivot
         double nrm2 = 0.0, below2 = 0.0, piv[5] = {0, 0, 0, 0, 0};
 #pragma unroll 1

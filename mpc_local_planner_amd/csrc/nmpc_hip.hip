@@ -29,6 +29,7 @@ namespace {
 template <int NW, bool SQP>
 struct GpuWave {
     static constexpr bool kSqp = SQP;
+    static constexpr bool kNeighbourLds = NW > 1;   // x_{k+1} of the next node: LDS exchange instead of a lane shuffle
     double *lds_;
     double *pol_;      // NW > 1: [2][4] reduction slots, then [128] exchange slots
     int flip_ = 0;
@@ -39,6 +40,9 @@ struct GpuWave {
     // value the optimiser must treat as unknown: keeps per-sweep address set-up inside the
     // interior-point loop instead of hoisted into ~45 live registers
     __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+    // a rounded fp64 value the compiler may not fold into the arithmetic around it (no contraction
+    // across this point: the result is the same in every instantiation of the kernel)
+    __device__ __forceinline__ double rounded(double v) { asm volatile("" : "+v"(v)); return v; }
     // Exchange through LDS between lanes of ONE wave: the LDS executes a wave's instructions in
     // issue order, so a write followed by a read needs no s_waitcnt and no s_barrier, only a
     // fence that keeps the compiler from moving LDS accesses across the exchange point.
@@ -276,6 +280,8 @@ struct GpuWave {
     }
 };
 
+enum KernelChoice { KERNEL_AUTO = 0, KERNEL_WAVE, KERNEL_QUAD };   // see use_quad_kernel
+
 struct KernelArgs {
     nmpcw::Problem pb;
     int B;
@@ -476,7 +482,7 @@ struct nmpc_handle {
     bool per_instance_N = false;
     unsigned char *d_reset, *d_mask;
     bool ordered;                 // launch longest-expected instances first (NMPC_SCHEDULE=0 turns it off)
-    bool quad;                    // NMPC_KERNEL=quad at creation: SQP-RTI up to N = 63 on the four-slot kernel
+    KernelChoice kernel;          // NMPC_KERNEL at creation (auto / wave / quad, see use_quad_kernel)
     const double *in_x0, *in_p;   // what the kernel reads (own buffers or caller's device buffers)
     double *out_ctrl;             // where the control records go (own buffer or the caller's device buffer)
     std::vector<double> h_traj;
@@ -505,19 +511,33 @@ static void fill_problem(const nmpc_config &c, int mode, int max_iter, double to
     pb.sqp_tol = tol;
 }
 
-// Which solve kernel.  The default is the one-instance-per-workgroup kernel (nmpc_wave_solver.h);
-// NMPC_KERNEL=quad selects the four-slots-per-workgroup kernel (nmpc_quad_solver.h) for SQP-RTI up to
-// N = 63 -- measured no faster at N = 40 (profiles/r2), kept as a tested
-// alternative.  Read when a handle is created / per call of nmpc_solve_static.
-static bool quad_kernel_requested()
+// Which solve kernel.  Two implement SQP-RTI up to N = 63: one instance per workgroup
+// (nmpc_wave_solver.h) and four slots per workgroup fed from a ticket queue (nmpc_quad_solver.h).
+// Measured (gpurun_out -> profiles/r2/quad_vs_wave.md): the four-slot kernel is 3-7 % faster where two
+// of its workgroups fit into a CU's LDS (N <= 43) and the sweeps are long enough to pay for its four
+// workgroup barriers per iteration (N >= 28), once the batch fills the chip several times over; it is
+// slower for short horizons, by 25 % where only one workgroup fits, and has the longer single-solve
+// latency.  NMPC_KERNEL=quad / wave forces one of them (read when a handle is created / per call of
+// nmpc_solve_static); everything else -- SQP mode, N > 63, per-instance horizons -- runs on the
+// one-instance kernel.
+static KernelChoice kernel_choice()
 {
     const char *e = getenv("NMPC_KERNEL");
-    return e && strcmp(e, "quad") == 0;
+    if (e && strcmp(e, "quad") == 0) return KERNEL_QUAD;
+    if (e && strcmp(e, "wave") == 0) return KERNEL_WAVE;
+    return KERNEL_AUTO;
+}
+static bool use_quad_kernel(KernelChoice c, int mode, int N, int B)
+{
+    if (mode != NMPC_MODE_RTI || nmpcw::waves_per_instance(N) != 1 || c == KERNEL_WAVE) return false;
+    if (c == KERNEL_QUAD) return true;
+    const size_t qbytes = (size_t)nmpcq::quad_lds_doubles(N) * sizeof(double);
+    return B >= 8192 && N >= 28 && 2 * qbytes <= 160 * 1024;
 }
 
 // Order kernel (optional: `hist` = iteration counts of the previous solve, `order` = its output) and
 // the solve kernel of one batch on `stream`.  Shared by nmpc_solve and nmpc_solve_static.
-static int launch_solve(KernelArgs &a, int mode, hipStream_t stream, const int *hist, int *order, bool quad)
+static int launch_solve(KernelArgs &a, int mode, hipStream_t stream, const int *hist, int *order, KernelChoice choice)
 {
     const int B = a.B, N = a.pb.N;
     a.order = nullptr;
@@ -527,7 +547,7 @@ static int launch_solve(KernelArgs &a, int mode, hipStream_t stream, const int *
         HIP_TRY(hipGetLastError());
         a.order = order;
     }
-    if (quad && mode == NMPC_MODE_RTI && nmpcw::waves_per_instance(N) == 1) {
+    if (use_quad_kernel(choice, mode, N, B)) {
         // SQP-RTI up to N = 63: workgroups of four waves, each wave a slot that draws instances from a
         // launch-wide ticket queue (nmpc_quad_solver.h); no more workgroups than can be resident at once
         // are needed -- later ones would find the queue empty
@@ -826,7 +846,7 @@ int nmpc_create(const nmpc_config *cfg, int capacity, int device, nmpc_handle **
     };
     const char *sched = getenv("NMPC_SCHEDULE");
     h->ordered = !(sched && sched[0] == '0');
-    h->quad = quad_kernel_requested();
+    h->kernel = kernel_choice();
     for (auto &a : allocs) *a.p = nullptr;
     bool ok = hip_ok(hipStreamCreate(&h->stream), "hipStreamCreate");
     for (auto &a : allocs) {
@@ -1001,7 +1021,7 @@ int nmpc_solve(nmpc_handle *h, int B, int mode, int max_iter, double tol)
     a.queue = h->d_queue;
     a.horizons = h->per_instance_N ? h->d_horizons : nullptr;
     // (the four-slot kernel sweeps four instances in lock step: one horizon per launch)
-    return launch_solve(a, mode, h->stream, h->ordered ? h->d_iters : nullptr, h->d_order, h->quad && !h->per_instance_N);
+    return launch_solve(a, mode, h->stream, h->ordered ? h->d_iters : nullptr, h->d_order, h->per_instance_N ? KERNEL_WAVE : h->kernel);
 }
 
 int nmpc_solve_static(const nmpc_config *cfg, int device, void *stream, int B, int cold, const double *d_x0,
@@ -1059,7 +1079,7 @@ int nmpc_solve_static(const nmpc_config *cfg, int device, void *stream, int B, i
     a.reset = sc->reset;
     a.queue = sc->queue;
     a.horizons = nullptr;
-    return launch_solve(a, NMPC_MODE_RTI, st, sc->hist, sc->order, quad_kernel_requested());
+    return launch_solve(a, NMPC_MODE_RTI, st, sc->hist, sc->order, kernel_choice());
 }
 
 int nmpc_sync(nmpc_handle *h)

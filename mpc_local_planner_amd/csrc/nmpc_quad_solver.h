@@ -30,10 +30,12 @@
 //
 // Status (measured on MI355X, profiles/r2): per solve this kernel issues 4.0x fewer
 // LDS instructions (19.7 k -> 5.0 k), keeps the LDS array busy 3.8x less (68 k -> 18 k cycles) and issues
-// 44 % fewer VALU instructions than the one-instance-per-workgroup kernel -- and is NOT faster at N = 40:
-// LDS capacity (19 KB per instance) and 256 VGPRs per slot wave both stop at eight instances per CU, so
-// a CU runs two sweep streams where the other kernel runs eight waves, and an interior-point iteration
-// of a workgroup (~24-30 us) costs what it costs there.  It is therefore opt-in (NMPC_KERNEL=quad).
+// 44 % fewer VALU instructions than the one-instance-per-workgroup kernel.  That buys 3-7 % of throughput,
+// not the factor the counters suggest: LDS capacity (19 KB per instance at N = 40) and 256 VGPRs per slot
+// wave both stop at eight instances per CU, so a CU runs two sweep streams where the other kernel runs
+// eight waves, and an interior-point iteration of a workgroup (~24-30 us) costs what it costs there.
+// nmpc_solve picks it where it wins: 28 <= N <= 43 (two workgroups per CU) and batches of 8192 and more
+// (nmpc_hip.hip: use_quad_kernel; NMPC_KERNEL=quad / wave forces a kernel).
 #pragma once
 
 #include "nmpc_wave_solver.h"
@@ -190,7 +192,7 @@ NMPC_DEV void solve_quad(W &w, const Problem &pb, const Batch &bt)
 #pragma unroll
                     for (int m = 0; m < 6; ++m) {
                         const double xn = w.shfl_down1(xb[m]);
-                        rb[m] = act ? (phi[m] - xn) : 0.0;
+                        rb[m] = w.rounded(act ? (w.rounded(phi[m]) - xn) : 0.0);
                     }
                     if (lane == 0) {   // fold the known dx_0 = x0 - x_0 into the first gap: b_0 += A_0 dx0
                         double d[6];

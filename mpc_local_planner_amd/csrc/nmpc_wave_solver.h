@@ -201,12 +201,15 @@ NMPC_DEV void rk4_sens(const Problem &pb, const double *x, const double *u, doub
         sVv += wgt * kVv; sVt += wgt * kVt; sV1 += wgt * kV1;
     }
     const double h6 = h / 6.0;
-    phi[0] = x[0] + h6 * sX;
-    phi[1] = x[1] + h6 * sY;
-    phi[2] = x[2] + h6 * sP;
-    phi[3] = x[3] + h6 * sV;
-    phi[4] = x[4] + h * u[0];
-    phi[5] = x[5] + h * u[1];
+    // (explicit fma: the shooting gap phi - x_{k+1} must round the same way in every instantiation of the
+    // kernel, whatever the compiler would choose to contract around it -- mixed-horizon launches are
+    // promised to be bit-identical to single-horizon ones)
+    phi[0] = fma(h6, sX, x[0]);
+    phi[1] = fma(h6, sY, x[1]);
+    phi[2] = fma(h6, sP, x[2]);
+    phi[3] = fma(h6, sV, x[3]);
+    phi[4] = fma(h, u[0], x[4]);
+    phi[5] = fma(h, u[1], x[5]);
     // columns: psi, v, delta, thr, u0, u1
     aX[0] = h6 * sXp; aX[1] = h6 * sXv; aX[2] = h6 * sXd; aX[3] = h6 * sXt; aX[4] = h6 * sX0; aX[5] = h6 * sX1;
     aY[0] = h6 * sYp; aY[1] = h6 * sYv; aY[2] = h6 * sYd; aY[3] = h6 * sYt; aY[4] = h6 * sY0; aY[5] = h6 * sY1;
@@ -264,9 +267,11 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
     bool tables_ready = false;
     double a33 = 0.0, a35 = 0.0, b31 = 0.0;   // constant entries of [B A] (row v)
 
-    // SQP mode (W::kSqp, a compile-time property of the policy): multipliers of the last QP, for
-    // the KKT residuals at the next iterate -- costate pi_k of this node, bound multipliers
-    double pik[6] = {0, 0, 0, 0, 0, 0}, lam_l[4] = {0, 0, 0, 0}, lam_u[4] = {0, 0, 0, 0};
+    // SQP mode (W::kSqp, a compile-time property of the policy): the multipliers of the last QP, needed
+    // for the KKT residuals at the next iterate, wait in the node's own stage of the LDS image --
+    // costate pi_k where the adjoint sweep left it (O_D), bound multipliers in the gain slots
+    // O_E..O_INV0+1, which nothing writes between two QPs.  Held in registers they were live across
+    // the integrator and cost 28 VGPRs of spills.
 
     for (sqp_it = 0;; ++sqp_it) {
         // ------------------------------------------------------------ linearise (stage layout)
@@ -277,19 +282,52 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
             sincos_bounded(io.p[4], &gp, &gpc);
             gp *= 9.81;
             double phi[6], aX[6], aY[6], aP[6], aV[6];
+            if (W::kNeighbourLds) {
+                // more than one wave: x_{k+1} comes through the gain slots of the column groups psi, v,
+                // delta of the node's stage (written next by the factor sweep, not by the linearisation
+                // of a neighbouring thread that runs ahead; node N: the same offsets of the exchange
+                // area, idle at this point) -- one barrier for all six values.  Stores and barrier come
+                // before the integrator so that its arithmetic and the shooting gap stay in one basic
+                // block, as with the lane shuffles of the one-wave kernel: the compiler then contracts
+                // multiply-adds the same way in both, and mixed-horizon launches stay bit-identical
+                double *mine = stg + node * ST + 2 * GS + G_K;
+                if (has_node) {         // (threads beyond node N hold a copy of x_N that is never stepped)
+                    st2(mine, xb[0], xb[1]); st2(mine + GS, xb[2], xb[3]); st2(mine + 2 * GS, xb[4], xb[5]);
+                }
+                w.sync();
+            }
             rk4_sens(pb, xb, ub_, gp, phi, aX, aY, aP, aV);
+            double xn[6];                                     // x_{k+1}
+            if (W::kNeighbourLds) {
+                const double *nxt = stg + (tid < N ? tid + 1 : node) * ST + 2 * GS + G_K;
+                const D2 n01 = ld2(nxt), n23 = ld2(nxt + GS), n45 = ld2(nxt + 2 * GS);
+                xn[0] = n01.x; xn[1] = n01.y; xn[2] = n23.x; xn[3] = n23.y; xn[4] = n45.x; xn[5] = n45.y;
+            } else {
+#pragma unroll
+                for (int m = 0; m < 6; ++m) xn[m] = w.shfl_down1(xb[m]);   // from the next lane
+            }
 #pragma unroll
             for (int m = 0; m < 6; ++m) {
-                const double xn = w.shfl_down1(xb[m]);       // x_{k+1} from the next lane
-                rb[m] = act ? (phi[m] - xn) : 0.0;
+                rb[m] = w.rounded(act ? (w.rounded(phi[m]) - xn[m]) : 0.0);
                 if (W::kSqp) kkt = fmax(kkt, fabs(rb[m]));                      // res_eq: shooting gaps
                 if (W::kSqp && tid == 0) kkt = fmax(kkt, fabs(io.x0[m] - xb[m]));   //         and x_0 = x0
             }
             double Atp[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // SQP mode: [B A]' pi_{k+1} in z ordering
+            double pik[6] = {0, 0, 0, 0, 0, 0}, lam_l[4] = {0, 0, 0, 0}, lam_u[4] = {0, 0, 0, 0};
             if (W::kSqp) {
-                double pn[6];
+                const bool have = sqp_it > 0;                 // no multipliers before the first QP
+                double pn[6];                                 // pi_{k+1}: nodes 1..N-1 carry one, pi_N = 0
+                {
+                    const double *own = stg + (actx ? tid : 0) * ST + O_D;
+                    const double *nx = stg + (tid + 1 < N ? tid + 1 : 0) * ST + O_D;
+                    const bool hn = have && tid + 1 < N, ho = have && actx;
 #pragma unroll
-                for (int m = 0; m < 6; ++m) pn[m] = w.shfl_down1(pik[m]);
+                    for (int m = 0; m < 6; ++m) { pn[m] = hn ? nx[m] : 0.0; pik[m] = ho ? own[m] : 0.0; }
+                    const double *lm = stg + (act ? tid : 0) * ST + O_E;
+                    const bool hl = have && act;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { lam_l[q] = hl ? lm[q] : 0.0; lam_u[q] = hl ? lm[4 + q] : 0.0; }
+                }
                 Atp[0] = aX[4] * pn[0] + aY[4] * pn[1] + aP[4] * pn[2] + h * pn[4];
                 Atp[1] = aX[5] * pn[0] + aY[5] * pn[1] + aP[5] * pn[2] + aV[5] * pn[3] + h * pn[5];
                 Atp[2] = pn[0];
@@ -830,10 +868,10 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
         // recursion of the QP's x-stationarity: pi_N = 0, pi_k = H_xx dx_k + q_k + A_k' pi_{k+1}
         // (+ bound multipliers on delta, thr), k = N-1 .. 1 -- one more serial sweep, with the
         // stage data of THIS linearisation still in LDS
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { lam_l[q] = ll[q]; lam_u[q] = lu[q]; }
         if (act) {
             double *sl = stg + tid * ST + O_D;
+            st2(sl - O_D + O_E, ll[0], ll[1]); st2(sl - O_D + O_E + 2, ll[2], ll[3]);       // bound multipliers
+            st2(sl - O_D + O_E + 4, lu[0], lu[1]); st2(sl - O_D + O_E + 6, lu[2], lu[3]);
             st2(sl + 0, Q00 * z[2] + Q01 * z[3] + Q02 * z[4] + g[2], Q01 * z[2] + Q11 * z[3] + g[3]);
             st2(sl + 2, Q02 * z[2] + Q22 * z[4] + g[4], Q33 * z[5] + g[5]);
             st2(sl + 4, Q44 * z[6] + g[6] - ll[2] + lu[2], Q55 * z[7] + g[7] - ll[3] + lu[3]);
@@ -857,13 +895,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 if (lane < 6) sk[O_D + c] = pi;
             }
         }
-        w.sync();
-        {
-            const double *src = stg + node * ST + O_D;
-#pragma unroll
-            for (int m = 0; m < 6; ++m) pik[m] = actx ? src[m] : 0.0;
-        }
-        w.sync();
+        w.sync();     // costates in place for the KKT test of the next iterate
     }
 
     // ---------------------------------------------------------------- write back

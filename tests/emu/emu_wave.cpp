@@ -81,15 +81,17 @@ void barrier(Barrier &b, int nthreads, int t)
     } while (b.gen == gen);
 }
 
-template <bool SQP>
+template <bool SQP, bool TWO = false>
 struct EmuWave {
-    static constexpr bool kSqp = SQP;   // same two instantiations as the GPU policy
+    static constexpr bool kSqp = SQP;   // same four instantiations as the GPU policy
+    static constexpr bool kNeighbourLds = TWO;
     int tid_;
     int tid() const { return tid_; }
     int lane() const { return tid_ & (WAVE - 1); }
     bool sweep_wave() const { return tid_ < WAVE; }
     double *lds() { return g_s->lds; }
     int opaque(int v) { return v; }
+    double rounded(double v) { return v; }
     void sched_fence() {}
     void fwd_fetch(const double *p1, const double *p3, const double *p2, double (&d)[9])
     {
@@ -199,8 +201,15 @@ struct EmuWave {
 
 void thread_main(int t)
 {
-    if (g_s->sqp) {
+    const bool two = g_s->nt > WAVE;
+    if (g_s->sqp && two) {
+        EmuWave<true, true> w{t};
+        nmpcw::solve_instance(w, *g_s->pb, *g_s->io);
+    } else if (g_s->sqp) {
         EmuWave<true> w{t};
+        nmpcw::solve_instance(w, *g_s->pb, *g_s->io);
+    } else if (two) {
+        EmuWave<false, true> w{t};
         nmpcw::solve_instance(w, *g_s->pb, *g_s->io);
     } else {
         EmuWave<false> w{t};

@@ -57,7 +57,7 @@ def solve_batch(cfg, x0, p, W=None, bnd=None, traj=None, cold=True, sqp_max_iter
     """cfg: any config struct with the nmpc_config field names.  sqp_max_iter = 0: one SQP-RTI
     iteration; > 0: SQP mode, at most that many iterations (KKT residuals <= sqp_tol).  kernel: "quad"
     (four instances per workgroup, nmpc_quad_solver.h), "wave" (one per workgroup, nmpc_wave_solver.h)
-    or "auto" = what nmpc_solve picks by default (wave; quad is opt-in, NMPC_KERNEL=quad).  Returns a dict like
+    or "auto" = the one-per-workgroup kernel (nmpc_solve itself picks by horizon and batch size).  Returns a dict like
     BatchSolver.get."""
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     p = np.ascontiguousarray(p, dtype=np.float64)

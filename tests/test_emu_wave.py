@@ -68,10 +68,12 @@ def test_emulated_wave_per_instance_weights_and_bounds(kernel):
         assert abs(g["cost"][i] - st.cost) <= 1e-9 * max(1.0, abs(st.cost))
 
 
-def test_emulated_wave_sqp_mode_converges_to_the_oracle_fixed_point():
-    N, B = 30, 4
+@pytest.mark.parametrize("N,B,gen", [(30, 4, sc.config2), (70, 2, sc.config4)])
+def test_emulated_wave_sqp_mode_converges_to_the_oracle_fixed_point(N, B, gen):
+    """N = 70: two waves per instance with idle threads behind node N (x_{k+1} and the multipliers of
+    the last QP then travel through the LDS image instead of lane shuffles)."""
     cfg = orc.default_config(N, 0.35)
-    x0, p = sc.config2(B)
+    x0, p = gen(B)
     g = emu.solve_batch(cfg, x0, p, sqp_max_iter=30, sqp_tol=1e-9)
     for i in range(B):
         xo, uo = orc.init_guess(cfg, x0[i])

@@ -289,6 +289,32 @@ def test_quad_kernel_full_batch_and_weights(monkeypatch):
     assert (np.abs(a["ipm_iters"] - b["ipm_iters"]) <= 1).all()
 
 
+def test_kernel_choice_by_batch_and_horizon(monkeypatch):
+    """Without NMPC_KERNEL the library picks the four-slot kernel for 28 <= N <= 43 and B >= 8192 and the
+    one-instance kernel otherwise (nmpc_hip.hip: use_quad_kernel).  Seen from outside: the automatic
+    choice is bit-identical to the forced kernel it should have picked, and both kernels agree to the bar."""
+    def run(N, B, kern):
+        if kern is None:
+            monkeypatch.delenv("NMPC_KERNEL", raising=False)
+        else:
+            monkeypatch.setenv("NMPC_KERNEL", kern)
+        s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
+        x0, p = sc.config2(B)
+        s.set_x0(x0)
+        s.set_params(p)
+        s.solve(B)
+        g = s.get(B)
+        s.close()
+        return g
+    for N, B, expect in ((40, 8192, "quad"), (40, 4096, "wave"), (20, 8192, "wave"), (44, 8192, "wave")):
+        auto, quad, wave = run(N, B, None), run(N, B, "quad"), run(N, B, "wave")
+        same = quad if expect == "quad" else wave
+        assert np.array_equal(auto["x"], same["x"]) and np.array_equal(auto["u"], same["u"]), (N, B)
+        assert not np.array_equal(quad["x"], wave["x"])          # (the two kernels round differently)
+        assert (_err(quad, wave["x"], wave["u"]) <= TOL_BAR * _scale(wave["x"], wave["u"])).all()
+        assert (auto["status"] == 0).mean() > 0.999
+
+
 def test_horizon_sweep_inside_one_launch():
     """nmpc_set_horizons (north_star: horizon sweeps per launch): a batch whose instances have horizons
     20 / 30 / 40 / 64 / 100 gives, instance by instance and bit for bit, what a handle created with that

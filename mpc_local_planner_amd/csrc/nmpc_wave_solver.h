@@ -296,7 +296,16 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 }
                 w.sync();
             }
-            rk4_sens(pb, xb, ub_, gp, phi, aX, aY, aP, aV);
+            if (W::kSqp) {
+                // SQP mode: the integrator sits in a loop, and everything in it that depends on the step
+                // size alone (the whole v-row of the sensitivities) would be hoisted out of that loop and
+                // then spilled -- the step size is made opaque per SQP iteration, so it is recomputed
+                Problem pl = pb;
+                pl.dt = w.rounded(pb.dt);
+                rk4_sens(pl, xb, ub_, gp, phi, aX, aY, aP, aV);
+            } else {
+                rk4_sens(pb, xb, ub_, gp, phi, aX, aY, aP, aV);
+            }
             double xn[6];                                     // x_{k+1}
             if (W::kNeighbourLds) {
                 const double *nxt = stg + (tid < N ? tid + 1 : node) * ST + 2 * GS + G_K;
@@ -878,7 +887,9 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
         }
         w.sync();
         if (w.sweep_wave()) {
-            const int c = lane < 6 ? lane : 5;      // lanes 0..5 own component c of the costate
+            // lanes 0..5 own component c of the costate (opaque: what depends on the lane alone is set up
+            // here, per sweep, and not kept in registers through the whole SQP loop)
+            const int c = w.opaque(lane < 6 ? lane : 5);
             const double a3 = c == 3 ? a33 : c == 5 ? a35 : 0.0;           // A[v][c]
             const double a4 = c == 4 ? 1.0 : 0.0, a5 = c == 5 ? 1.0 : 0.0;  // A[delta][c], A[thr][c]
             double pi = 0.0;

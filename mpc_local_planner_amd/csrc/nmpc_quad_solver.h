@@ -142,12 +142,9 @@ NMPC_DEV void solve_quad(W &w, const Problem &pb, const Batch &bt)
         a33 = w.uniform(aV[1]); a35 = w.uniform(aV[3]); b31 = w.uniform(aV[5]);
     }
 
-    // per-lane view of the sweeps (only the sweeper wave uses it): row = instance, j = column
-    const int row = lane >> 4, j16 = lane & 15;
-    double *const rct = w.lds() + row * IS;
-    double *const rstg = rct + ST;
-    double *const rxa = rct + (N + 1) * ST;
-    double *const rlast = rstg + (N - 1) * ST;
+    // per-lane view of the sweeps (only the sweeper wave uses it): row = instance, j = column.  The
+    // addresses derived from it are set up per pass (opaque lane index), not held through the slot loop
+    const int j16 = lane & 15;
 
     for (;;) {
         double mu = 0.0;
@@ -188,7 +185,11 @@ NMPC_DEV void solve_quad(W &w, const Problem &pb, const Batch &bt)
                     sincos_bounded(io.p[4], &gp, &gpc);
                     gp *= 9.81;
                     double phi[6], aX[6], aY[6], aP[6], aV[6];
-                    rk4_sens(pb, xb, ub_, gp, phi, aX, aY, aP, aV);
+                    // (step size opaque per instance: what depends on it alone -- the v-row of the
+                    // sensitivities -- would otherwise be computed ahead of the slot loop and spilled)
+                    Problem pl = pb;
+                    pl.dt = w.rounded(pb.dt);
+                    rk4_sens(pl, xb, ub_, gp, phi, aX, aY, aP, aV);
 #pragma unroll
                     for (int m = 0; m < 6; ++m) {
                         const double xn = w.shfl_down1(xb[m]);
@@ -390,6 +391,11 @@ NMPC_DEV void solve_quad(W &w, const Problem &pb, const Batch &bt)
         for (int pass = 0; pass < 2; ++pass) {
             if (w.sweeper()) {
                 w.sweep_priority(true);
+                const int row = w.opaque(lane) >> 4;
+                double *const rct = w.lds() + row * IS;
+                double *const rstg = rct + ST;
+                double *const rxa = rct + (N + 1) * ST;
+                double *const rlast = rstg + (N - 1) * ST;
                 if (pass == 0) {
                     // ---- factor sweep of the four instances, k = N-1 .. 0
                     const int j = w.opaque(j16);

@@ -377,6 +377,42 @@ def test_horizon_sweep_inside_one_launch():
     s.close()
 
 
+@pytest.mark.parametrize("NMAX", [63, 127])
+def test_horizon_sweep_edge_horizons(NMAX):
+    """Per-instance horizons at the edges -- 1, 2, the last one-wave horizon and the first two-wave ones,
+    the handle's own maximum -- inside a one-wave (NMAX = 63) and a two-wave (NMAX = 127) launch: three
+    calls (cold, warm, warm), bit-identical to handles created with that horizon, SQP mode included."""
+    hs = [h for h in (1, 2, 3, 62, 63, 64, 65, 126, 127) if h <= NMAX]
+    B = 6 * len(hs)
+    horizons = np.array(hs, dtype=np.int32)[np.arange(B) % len(hs)]
+    x0, p = sc.config2(B, start=300)
+    for mode_kw in ({}, dict(mode=capi.MODE_SQP, max_iter=4, tol=1e-12)):
+        s = capi.BatchSolver(N=NMAX, dt=0.35, capacity=B)
+        s.set_x0(x0)
+        s.set_params(p)
+        s.set_horizons(horizons)
+        mixed = []
+        for call in range(3):
+            s.solve(B, **mode_kw)
+            mixed.append(s.get(B))
+        s.close()
+        for n in hs:
+            sel = np.where(horizons == n)[0]
+            one = capi.BatchSolver(N=int(n), dt=0.35, capacity=len(sel))
+            one.set_x0(x0[sel])
+            one.set_params(p[sel])
+            for call in range(3):
+                one.solve(len(sel), **mode_kw)
+                g = one.get(len(sel))
+                m = mixed[call]
+                assert np.array_equal(m["x"][sel][:, :n + 1], g["x"]), (n, call, mode_kw)
+                assert np.array_equal(m["u"][sel][:, :n], g["u"]), (n, call, mode_kw)
+                assert np.array_equal(m["status"][sel], g["status"])
+                assert np.array_equal(m["ipm_iters"][sel], g["ipm_iters"])
+                assert np.array_equal(m["sqp_iters"][sel], g["sqp_iters"])
+            one.close()
+
+
 def test_gather_controls_over_rccl_single_rank():
     """nmpc_gather_controls through the C ABI with a real RCCL communicator.  The test box has one GPU,
     so the communicator has one rank (ncclCommInitAll): the gathered block must equal this rank's control

@@ -482,6 +482,7 @@ struct nmpc_handle {
     bool per_instance_N = false;
     unsigned char *d_reset, *d_mask;
     bool ordered;                 // launch longest-expected instances first (NMPC_SCHEDULE=0 turns it off)
+    int hist_B = 0;               // instances [0, hist_B) may have an iteration history (0: none, the order kernel is skipped)
     KernelChoice kernel;          // NMPC_KERNEL at creation (auto / wave / quad, see use_quad_kernel)
     const double *in_x0, *in_p;   // what the kernel reads (own buffers or caller's device buffers)
     double *out_ctrl;             // where the control records go (own buffer or the caller's device buffer)
@@ -975,6 +976,7 @@ int nmpc_reset(nmpc_handle *h, const uint8_t *mask, int B)
                        mask ? h->d_mask : nullptr, B, h->d_iters);
     HIP_TRY(hipGetLastError());
     if (mask) HIP_TRY(hipStreamSynchronize(h->stream));
+    else if (B >= h->hist_B) h->hist_B = 0;      // everything that had a history has lost it
     return NMPC_OK;
 }
 
@@ -1021,7 +1023,9 @@ int nmpc_solve(nmpc_handle *h, int B, int mode, int max_iter, double tol)
     a.queue = h->d_queue;
     a.horizons = h->per_instance_N ? h->d_horizons : nullptr;
     // (the four-slot kernel sweeps four instances in lock step: one horizon per launch)
-    return launch_solve(a, mode, h->stream, h->ordered ? h->d_iters : nullptr, h->d_order, h->per_instance_N ? KERNEL_WAVE : h->kernel);
+    const int *hist = (h->ordered && h->hist_B > 0) ? h->d_iters : nullptr;   // nothing to order by after a full reset
+    if (B > h->hist_B) h->hist_B = B;
+    return launch_solve(a, mode, h->stream, hist, h->d_order, h->per_instance_N ? KERNEL_WAVE : h->kernel);
 }
 
 int nmpc_solve_static(const nmpc_config *cfg, int device, void *stream, int B, int cold, const double *d_x0,
@@ -1055,8 +1059,7 @@ int nmpc_solve_static(const nmpc_config *cfg, int device, void *stream, int B, i
     // the array keeps the previous call's contents: flags are rewritten for this batch, and a cold
     // batch has no history worth ordering by (zero = identity order)
     HIP_TRY(hipMemsetAsync(sc->reset, cold ? 1 : 0, (size_t)B, st));
-    if (cold) HIP_TRY(hipMemsetAsync(sc->hist, 0, sizeof(int) * (size_t)B, st));
-    else HIP_TRY(hipMemcpyAsync(sc->hist, d_ipm_iters, sizeof(int) * (size_t)B, hipMemcpyDeviceToDevice, st));
+    if (!cold) HIP_TRY(hipMemcpyAsync(sc->hist, d_ipm_iters, sizeof(int) * (size_t)B, hipMemcpyDeviceToDevice, st));
     KernelArgs a;
     fill_problem(*cfg, NMPC_MODE_RTI, 1, 0.0, a.pb);
     a.B = B;
@@ -1079,7 +1082,7 @@ int nmpc_solve_static(const nmpc_config *cfg, int device, void *stream, int B, i
     a.reset = sc->reset;
     a.queue = sc->queue;
     a.horizons = nullptr;
-    return launch_solve(a, NMPC_MODE_RTI, st, sc->hist, sc->order, kernel_choice());
+    return launch_solve(a, NMPC_MODE_RTI, st, cold ? nullptr : sc->hist, sc->order, kernel_choice());
 }
 
 int nmpc_sync(nmpc_handle *h)

@@ -2,6 +2,7 @@
 // path-tracking NMPC solver.  One 64-lane wavefront (= one 64-thread workgroup)
 // per OCP instance; see nmpc_wave_solver.h for the in-wave work mapping.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <dlfcn.h>
 
 #include <cstdio>
@@ -26,12 +27,13 @@ namespace {
 // NW = waves per OCP instance (= per workgroup): 1 for N <= 63, 2 for N <= 127.  The sweeps always
 // run on the first wave; the other wave only takes part in the stage-layout work.
 // SQP = full SQP mode (the RTI instantiation carries none of the KKT-residual / costate code).
-template <int NW, bool SQP>
+template <int NW, bool SQP, bool COMPACT = false>
 struct GpuWave {
+    using Layout = typename std::conditional<COMPACT, nmpcw::Layout48, nmpcw::Layout54>::type;
     static constexpr bool kSqp = SQP;
     static constexpr bool kNeighbourLds = NW > 1;   // x_{k+1} of the next node: LDS exchange instead of a lane shuffle
     double *lds_;
-    double *pol_;      // NW > 1: [2][4] reduction slots, then [128] exchange slots
+    double *pol_;      // NW > 1: [2][4] reduction slots
     int flip_ = 0;
     __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
     __device__ __forceinline__ int lane() const { return (int)threadIdx.x & 63; }
@@ -182,6 +184,55 @@ struct GpuWave {
               [adg] "v"(lds_addr(dg)), [aab] "v"(lds_addr(ab)), [kfw] "v"(lds_addr(kfw))
             : "memory");
     }
+    // the same two with the pair (ab[0], ab2[0]) not necessarily adjacent (Layout48: rows of -inv(Huu) in spare slots)
+    __device__ __forceinline__ void bwd_fetch2(const double *tv, const double *dg, const double *ab, const double *ab2,
+                                               double (&d)[6])
+    {
+        asm volatile(
+            "ds_read_b64 %0, %6\n\t"
+            "ds_read_b64 %1, %6 offset:8\n\t"
+            "ds_read_b64 %2, %6 offset:16\n\t"
+            "ds_read_b64 %3, %7\n\t"
+            "ds_read_b64 %4, %8\n\t"
+            "ds_read_b64 %5, %9\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5])
+            : "v"(lds_addr(tv)), "v"(lds_addr(dg)), "v"(lds_addr(ab)), "v"(lds_addr(ab2))
+            : "memory");
+    }
+    __device__ __forceinline__ void bwd_stage2(double (&cur)[6], double (&nxt)[6], const double *tv, const double *dg,
+                                               const double *ab, const double *ab2, double *kfw, double cb0, double cb1,
+                                               double cb2, double keep, double &res)
+    {
+        double t;
+        asm volatile(
+            "ds_read_b64 %[n0], %[atv]\n\t"
+            "ds_read_b64 %[n1], %[atv] offset:8\n\t"
+            "ds_read_b64 %[n2], %[atv] offset:16\n\t"
+            "ds_read_b64 %[n3], %[adg]\n\t"
+            "ds_read_b64 %[n4], %[aab]\n\t"
+            "ds_read_b64 %[n5], %[aab2]\n\t"
+            "v_fmac_f64_dpp %[g], %[res], %[t0] row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b64 %[t], 0\n\t"
+            "v_fmac_f64_dpp %[t], %[res], %[t1] row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[g], %[res], %[t2] row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[t], %[res], %[cb0] row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[g], %[res], %[cb1] row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[t], %[res], %[cb2] row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f64 %[g], %[g], %[t]\n\t"
+            "v_mul_f64 %[res], %[keep], %[g]\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64_dpp %[res], %[g], %[ka] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[res], %[g], %[kb] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+            "ds_write_b64 %[kfw], %[res]\n\t"
+            "s_waitcnt lgkmcnt(1)"
+            : [n0] "=&v"(nxt[0]), [n1] "=&v"(nxt[1]), [n2] "=&v"(nxt[2]), [n3] "=&v"(nxt[3]), [n4] "=&v"(nxt[4]),
+              [n5] "=&v"(nxt[5]), [t] "=&v"(t), [res] "+v"(res), [g] "+v"(cur[3])
+            : [t0] "v"(cur[0]), [t1] "v"(cur[1]), [t2] "v"(cur[2]), [ka] "v"(cur[4]), [kb] "v"(cur[5]),
+              [cb0] "v"(cb0), [cb1] "v"(cb1), [cb2] "v"(cb2), [keep] "v"(keep), [atv] "v"(lds_addr(tv)),
+              [adg] "v"(lds_addr(dg)), [aab] "v"(lds_addr(ab)), [aab2] "v"(lds_addr(ab2)), [kfw] "v"(lds_addr(kfw))
+            : "memory");
+    }
     // issue priority of the wave while it runs the serial sweeps: the other wave of the SIMD, when it is
     // in its element-wise phase, has independent work to fill the gaps with (+0.3 % cold, +1.2 % warm)
     __device__ __forceinline__ void sweep_priority(bool on)
@@ -215,17 +266,9 @@ struct GpuWave {
         const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
         return __hiloint2double(hi, lo);
     }
-    // value of thread tid+1 (the last thread gets its own)
-    __device__ __forceinline__ double shfl_down1(double v)
-    {
-        if (NW == 1) return __shfl_down(v, 1, 64);
-        double *ex = pol_ + 8;
-        ex[threadIdx.x] = v;
-        __syncthreads();
-        const double r = ex[threadIdx.x + 1 < 64 * NW ? threadIdx.x + 1 : threadIdx.x];
-        __syncthreads();
-        return r;
-    }
+    // value of lane + 1 (the last lane gets its own); one-wave instances only -- two-wave instances
+    // exchange through the LDS image (kNeighbourLds)
+    __device__ __forceinline__ double shfl_down1(double v) { return __shfl_down(v, 1, 64); }
     // Reductions over all threads of the instance without LDS traffic inside a wave: four DPP
     // butterfly steps (xor 1, xor 2, mirror within 8, mirror within 16) leave each 16-lane row's
     // result in all its lanes; the four row results are read with v_readlane and combined.
@@ -295,7 +338,7 @@ struct KernelArgs {
     const int *horizons;   // per-instance horizon 1..pb.N (nmpc_set_horizons), or null: pb.N for all
 };
 
-template <int NW, bool SQP>
+template <int NW, bool SQP, bool COMPACT = false>
 __global__ void __launch_bounds__(64 * NW, 2) nmpc_solve_kernel(KernelArgs a)
 {
     extern __shared__ double lds[];
@@ -314,7 +357,7 @@ __global__ void __launch_bounds__(64 * NW, 2) nmpc_solve_kernel(KernelArgs a)
     io.cost = a.cost + inst;
     io.cold = a.reset[inst];
     io.N = a.horizons ? a.horizons[inst] : 0;
-    GpuWave<NW, SQP> w{lds, lds + (a.pb.N + 1) * nmpcw::ST + nmpcw::X_SIZE};
+    GpuWave<NW, SQP, COMPACT> w{lds, lds + (a.pb.N + 1) * GpuWave<NW, SQP, COMPACT>::Layout::ST + nmpcw::X_SIZE};
     nmpcw::solve_instance(w, a.pb, io);
     // instances that did not return success restart cold next time, whatever the status (NaN, QP
     // failure, SQP iteration limit): the reference re-initialises on every status != ACADOS_SUCCESS
@@ -566,11 +609,15 @@ static int launch_solve(KernelArgs &a, int mode, hipStream_t stream, const int *
     const size_t lds_bytes = (size_t)nmpcw::lds_doubles(N) * sizeof(double);
     // one workgroup per instance: one wave (lane = shooting node) up to N = 63, two waves beyond
     const bool one = nmpcw::waves_per_instance(N) == 1;
+    // (two waves: the 48-double stage where it lets one more instance reside per CU, nmpcw::compact_layout)
+    const bool compact = nmpcw::compact_layout(N);
     if (mode == NMPC_MODE_RTI) {
         if (one) hipLaunchKernelGGL((nmpc_solve_kernel<1, false>), dim3(B), dim3(64), lds_bytes, stream, a);
+        else if (compact) hipLaunchKernelGGL((nmpc_solve_kernel<2, false, true>), dim3(B), dim3(128), lds_bytes, stream, a);
         else hipLaunchKernelGGL((nmpc_solve_kernel<2, false>), dim3(B), dim3(128), lds_bytes, stream, a);
     } else {
         if (one) hipLaunchKernelGGL((nmpc_solve_kernel<1, true>), dim3(B), dim3(64), lds_bytes, stream, a);
+        else if (compact) hipLaunchKernelGGL((nmpc_solve_kernel<2, true, true>), dim3(B), dim3(128), lds_bytes, stream, a);
         else hipLaunchKernelGGL((nmpc_solve_kernel<2, true>), dim3(B), dim3(128), lds_bytes, stream, a);
     }
     HIP_TRY(hipGetLastError());
@@ -587,9 +634,11 @@ static int raise_lds_limit(int N)
     }
     const int lds_bytes = nmpcw::lds_doubles(N) * (int)sizeof(double);
     if (lds_bytes <= 48 * 1024) return NMPC_OK;
-    const bool one = nmpcw::waves_per_instance(N) == 1;
-    const void *fns[2] = {one ? (const void *)nmpc_solve_kernel<1, false> : (const void *)nmpc_solve_kernel<2, false>,
-                          one ? (const void *)nmpc_solve_kernel<1, true> : (const void *)nmpc_solve_kernel<2, true>};
+    const bool one = nmpcw::waves_per_instance(N) == 1, compact = nmpcw::compact_layout(N);
+    const void *fns[2] = {one ? (const void *)nmpc_solve_kernel<1, false>
+                              : compact ? (const void *)nmpc_solve_kernel<2, false, true> : (const void *)nmpc_solve_kernel<2, false>,
+                          one ? (const void *)nmpc_solve_kernel<1, true>
+                              : compact ? (const void *)nmpc_solve_kernel<2, true, true> : (const void *)nmpc_solve_kernel<2, true>};
     for (const void *fn : fns)
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     return NMPC_OK;

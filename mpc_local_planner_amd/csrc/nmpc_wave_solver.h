@@ -102,6 +102,31 @@ constexpr int O_INV1 = 52;
 // input view of the factor sweep, overlaying the gain/inverse slots it writes afterwards
 constexpr int I_GAM01 = 12, I_GAM23 = 18, I_Q0 = 24, I_Q2 = 30;   // (gam0,gam1) (gam2,gam3) (Q00,Q01) (Q02,-)
 constexpr int I_G = 36;         // G[8]
+// The constants above are the 54-double stage (Layout54), used by every one-wave kernel.  Two-wave
+// instances whose LDS image would otherwise cost a resident instance per CU (N = 91..100: three instead
+// of four, N = 121..127: two instead of three) use the 48-double stage (Layout48): the same six column
+// groups, but kff and the rows of -inv(Huu) live in the groups' spare slots (single doubles, six apart)
+// and the gradient of the factor input is split between the O_E pairs and four spare slots.  Its stride
+// of 96 dwords puts every other stage on the same banks (4-way conflicts on the stage-layout accesses);
+// at these horizons the sweeps are > 99 % of the LDS traffic, and they address within one stage.
+struct Layout54 {
+    static constexpr int ST = 54, GS = 6, G_K = 0, G_XY = 2, O_E = 36, O_D = 44;
+    static constexpr int KFF0 = 40, KFF1 = 41;                               // kff
+    static constexpr int INV00 = 42, INV01 = 43, INV10 = 52, INV11 = 53;     // rows of -inv(Huu)
+    static constexpr bool kPairOut = true;      // kff and each row of -inv(Huu) are 16-byte pairs
+    static constexpr int I_GAM01 = 12, I_GAM23 = 18, I_Q0 = 24, I_Q2 = 30;
+    static constexpr int g_off(int i) { return 36 + i; }                     // gradient entry i of the factor input
+    static constexpr int LAM0 = 36, LAM1 = 38, LAM2 = 40, LAM3 = 42;         // SQP mode: bound multipliers between two QPs (pairs)
+};
+struct Layout48 {
+    static constexpr int ST = 48, GS = 6, G_K = 0, G_XY = 2, O_E = 36, O_D = 40;
+    static constexpr int KFF0 = 5, KFF1 = 11;
+    static constexpr int INV00 = 17, INV01 = 23, INV10 = 29, INV11 = 35;
+    static constexpr bool kPairOut = false;
+    static constexpr int I_GAM01 = 12, I_GAM23 = 18, I_Q0 = 24, I_Q2 = 30;
+    static constexpr int g_off(int i) { return i < 4 ? 36 + i : 5 + 6 * (i - 4); }
+    static constexpr int LAM0 = 36, LAM1 = 38, LAM2 = 46, LAM3 = 30;         // O_E, the pad pair of O_D, gain pair of column thr
+};
 // pseudo-stage -1: its groups hold rows v,delta,thr of the six variable columns (constants) in
 // the (X,Y,psi) positions; its O_D holds z_0
 // exchange area after the stages
@@ -117,10 +142,22 @@ constexpr int X_UNITB = 161;    // (1,0,0),-,(0,1,0): the unit columns again at 
                                 // odd, even, odd -- different banks at every stage alignment
 constexpr int X_SIZE = 168;
 // horizons beyond 63 use two waves per instance (lane = node needs 128 threads); their cross-wave
-// reductions and the x_{k+1} hand-over go through a small extra area owned by the wave policy
-constexpr int X_POLICY = 8 + 128;
+// reductions go through a small extra area owned by the wave policy
+constexpr int X_POLICY = 8;
 constexpr int waves_per_instance(int N) { return N + 1 <= 64 ? 1 : 2; }
-constexpr int lds_doubles(int N) { return (N + 1) * ST + X_SIZE + (waves_per_instance(N) > 1 ? X_POLICY : 0); }
+constexpr int lds_doubles_st(int st, int N) { return (N + 1) * st + X_SIZE + (waves_per_instance(N) > 1 ? X_POLICY : 0); }
+// instances of a two-wave kernel that fit into a CU: 160 KB of LDS (allocated in 512-byte steps), 8 waves at 256 VGPRs
+constexpr int two_wave_instances_per_cu(int st, int N)
+{
+    const int bytes = (lds_doubles_st(st, N) * 8 + 511) / 512 * 512;
+    return 160 * 1024 / bytes < 4 ? 160 * 1024 / bytes : 4;
+}
+// the 48-double stage where (and only where) it lets one more instance reside per CU
+constexpr bool compact_layout(int N)
+{
+    return waves_per_instance(N) > 1 && two_wave_instances_per_cu(Layout48::ST, N) > two_wave_instances_per_cu(Layout54::ST, N);
+}
+constexpr int lds_doubles(int N) { return lds_doubles_st(compact_layout(N) ? Layout48::ST : Layout54::ST, N); }
 
 // 16-byte pair access (ds_read_b128 / ds_write_b128) and a single load that is never merged
 struct alignas(16) D2 { double x, y; };
@@ -221,12 +258,16 @@ NMPC_DEV void rk4_sens(const Problem &pb, const double *x, const double *u, doub
 #define NMPC_ZQ(a, q) ((q) == 0 ? (a)[0] : (q) == 1 ? (a)[1] : (q) == 2 ? (a)[6] : (a)[7])
 // variable-column index of z index j (u0,u1,-,-,psi,v,delta,thr) -> 0,1,-,-,2,3,4,5
 #define NMPC_VCOL(j) ((j) < 2 ? (j) : (j) - 2)
-// stage offset of the gain pair (K0[c],K1[c]), c = X,Y,psi,v,delta,thr; c = 6: (kff0,kff1)
-#define NMPC_KOFF(c) ((c) < 2 ? O_E + 2 * (c) : (c) < 6 ? GS * (c) + G_K : O_KFF)
+// stage offset of the gain pair (K0[c],K1[c]), c = X,Y,psi,v,delta,thr
+#define NMPC_KOFF(c) ((c) < 2 ? O_E + 2 * (c) : GS * (c) + G_K)
 
 template <class W>
 NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
 {
+    // stage layout of this instantiation (shadows the namespace-level constants of Layout54)
+    using L = typename W::Layout;
+    constexpr int ST = L::ST, GS = L::GS, G_K = L::G_K, G_XY = L::G_XY, O_E = L::O_E, O_D = L::O_D;
+    constexpr int I_GAM01 = L::I_GAM01, I_GAM23 = L::I_GAM23, I_Q0 = L::I_Q0, I_Q2 = L::I_Q2;
     const int tid = w.tid();     // thread in the workgroup = shooting node in stage layout
     const int lane = w.lane();   // lane in the wave (the sweeps run on the first wave only)
     // the instance's own horizon: its nodes are threads 0..N, its stages the first N of the LDS image
@@ -269,8 +310,8 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
 
     // SQP mode (W::kSqp, a compile-time property of the policy): the multipliers of the last QP, needed
     // for the KKT residuals at the next iterate, wait in the node's own stage of the LDS image --
-    // costate pi_k where the adjoint sweep left it (O_D), bound multipliers in the gain slots
-    // O_E..O_INV0+1, which nothing writes between two QPs.  Held in registers they were live across
+    // costate pi_k where the adjoint sweep left it (O_D), bound multipliers in slots nothing writes
+    // between two QPs (L::LAM0..3).  Held in registers they were live across
     // the integrator and cost 28 VGPRs of spills.
 
     for (sqp_it = 0;; ++sqp_it) {
@@ -332,10 +373,11 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     const bool hn = have && tid + 1 < N, ho = have && actx;
 #pragma unroll
                     for (int m = 0; m < 6; ++m) { pn[m] = hn ? nx[m] : 0.0; pik[m] = ho ? own[m] : 0.0; }
-                    const double *lm = stg + (act ? tid : 0) * ST + O_E;
+                    const double *lm = stg + (act ? tid : 0) * ST;
                     const bool hl = have && act;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { lam_l[q] = hl ? lm[q] : 0.0; lam_u[q] = hl ? lm[4 + q] : 0.0; }
+                    const D2 l01 = ld2(lm + L::LAM0), l23 = ld2(lm + L::LAM1), u01 = ld2(lm + L::LAM2), u23 = ld2(lm + L::LAM3);
+                    lam_l[0] = hl ? l01.x : 0.0; lam_l[1] = hl ? l01.y : 0.0; lam_l[2] = hl ? l23.x : 0.0; lam_l[3] = hl ? l23.y : 0.0;
+                    lam_u[0] = hl ? u01.x : 0.0; lam_u[1] = hl ? u01.y : 0.0; lam_u[2] = hl ? u23.x : 0.0; lam_u[3] = hl ? u23.y : 0.0;
                 }
                 Atp[0] = aX[4] * pn[0] + aY[4] * pn[1] + aP[4] * pn[2] + h * pn[4];
                 Atp[1] = aX[5] * pn[0] + aY[5] * pn[1] + aP[5] * pn[2] + aV[5] * pn[3] + h * pn[5];
@@ -517,8 +559,14 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     // across lanes (8-byte accesses are 2-way)
                     st2(sl + I_GAM01, gam[0], gam[1]); st2(sl + I_GAM23, gam[2], gam[3]);
                     st2(sl + I_Q0, Q00, Q01);          st2(sl + I_Q2, Q02, 0.0);
+                    if (L::kPairOut) {
 #pragma unroll
-                    for (int m = 0; m < 8; m += 2) st2(sl + I_G + m, G[m], G[m + 1]);
+                        for (int m = 0; m < 8; m += 2) st2(sl + L::g_off(m), G[m], G[m + 1]);
+                    } else {
+                        st2(sl + L::g_off(0), G[0], G[1]); st2(sl + L::g_off(2), G[2], G[3]);
+#pragma unroll
+                        for (int m = 4; m < 8; ++m) sl[L::g_off(m)] = G[m];
+                    }
                     st2(sl + O_D + 0, rb[0], rb[1]); st2(sl + O_D + 2, rb[2], 0.0);
                     st2(sl + O_D + 4, rb[3], rb[4]); st2(sl + O_D + 6, rb[5], 0.0);
                 }
@@ -568,7 +616,10 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 int sTab = 0;
                 {
                     int off = -1;
-                    if (f2j == 8) off = I_G + f2i;                           // gradient column
+                    if (f2j == 8) {                                          // gradient column
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) if (f2i == i) off = L::g_off(i);
+                    }
                     else if (f2i == f2j) {
                         if (f2i == 0) { hconst = R00; off = I_GAM01; }
                         if (f2i == 1) { hconst = R11; off = I_GAM01 + 1; }
@@ -586,14 +637,21 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 double *const pHw = (f2on && f2i < 2) ? xa + X_HU + 2 * f2j + f2i : xa + X_DUM;
                 const double *const pHj = xa + X_HU + 2 * f2j;
                 const double *const pHi = xa + X_HU + 2 * f2i;
-                double *pPw1 = xa + X_DUM, *pPw2 = xa + X_DUM, *kw = xa + X_DUM;
+                // (kw, kw2): where this lane's pair (K0, K1) goes -- gains of a column, kff, a row of -inv(Huu);
+                // one 16-byte store where the layout keeps them side by side, two 8-byte stores otherwise
+                double *pPw1 = xa + X_DUM, *pPw2 = xa + X_DUM, *kw = xa + X_DUM, *kw2 = xa + X_DUM + 1;
                 int sKw = 0;
                 if (f2on && f2i >= 2) {
                     pPw1 = xa + X_P + (f2i - 2) * 8 + (f2j - 2);
                     if (f2j <= 7) pPw2 = xa + X_P + (f2j - 2) * 8 + (f2i - 2);
-                    if (f2i == 2) { kw = last + NMPC_KOFF(f2j - 2); sKw = ST; }
+                    if (f2i == 2) {
+                        if (f2j < 8) { kw = last + NMPC_KOFF(f2j - 2); kw2 = kw + 1; }
+                        else { kw = last + L::KFF0; kw2 = last + L::KFF1; }
+                        sKw = ST;
+                    }
                 }
-                if (fl == 44 || fl == 45) { kw = last + (fl == 44 ? O_INV0 : O_INV1); sKw = ST; }
+                if (fl == 44) { kw = last + L::INV00; kw2 = last + L::INV01; sKw = ST; }
+                if (fl == 45) { kw = last + L::INV10; kw2 = last + L::INV11; sKw = ST; }
                 // rows v,delta,thr of column i are constants: loaded once per sweep
                 const D2 v01 = ld2(pBotI);
                 const double v2 = pBotI[2];
@@ -641,9 +699,11 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     const double Pn = Hv + hi.x * K0 + hi.y * K1;
                     *pPw1 = Pn;
                     *pPw2 = Pn;
-                    st2(kw, K0, K1);
+                    if (L::kPairOut) st2(kw, K0, K1);
+                    else { *kw = K0; *kw2 = K1; }
                     w.wsync();
                     kw -= sKw;
+                    if (!L::kPairOut) kw2 -= sKw;
                 };
 #pragma unroll 1
                 for (int k = (NMPC_PROF_SKIP & 1) ? -1 : N - 1; k >= 0; k -= 2) {
@@ -679,9 +739,10 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     const int sDgV = ST;
                     // res = keep * hc + ab.x * hc[0] + ab.y * hc[1]: lanes >= 2 form p_new with their gain
                     // pair (K0,K1); lanes 0,1 form kff = -(inv hu) with row vl of -inv
-                    const double *ab = vl >= 2 ? last + NMPC_KOFF(vl - 2) : last + (vl == 0 ? O_INV0 : O_INV1);
+                    const double *ab = vl >= 2 ? last + NMPC_KOFF(vl - 2) : last + (vl == 0 ? L::INV00 : L::INV10);
+                    const double *ab2 = vl >= 2 ? ab + 1 : last + (vl == 0 ? L::INV01 : L::INV11);   // (second entry: only where not adjacent)
                     const double keep = vl >= 2 ? 1.0 : 0.0;
-                    double *kfw = bl < 2 ? last + O_KFF + bl : xa + X_DUM;
+                    double *kfw = bl < 2 ? last + (bl == 0 ? L::KFF0 : L::KFF1) : xa + X_DUM;
                     const int sKfw = bl < 2 ? ST : 0;
                     // rows v,delta,thr of column vl
                     const double cb0 = vl == 1 ? b31 : vl == 5 ? a33 : vl == 7 ? a35 : 0.0;
@@ -691,16 +752,30 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     // LDS latency then hides behind the multiply-add chain of the current stage
                     double res = 0.0;
                     double da[6], db[6];      // column (X,Y,psi), gradient entry, gain pair
-                    w.bwd_fetch(tv, dg, ab, da);
+                    if (L::kPairOut) {
+                        w.bwd_fetch(tv, dg, ab, da);
 #pragma unroll 1
-                    for (int k = (NMPC_PROF_SKIP & 2) ? -1 : N - 1; k >= 0; k -= 2) {
-                        tv -= sTopV; dg -= sDgV; ab -= ST;
-                        w.bwd_stage(da, db, tv, dg, ab, kfw, cb0, cb1, cb2, keep, res);
-                        kfw -= sKfw;
-                        if (k == 0) break;
-                        tv -= sTopV; dg -= sDgV; ab -= ST;
-                        w.bwd_stage(db, da, tv, dg, ab, kfw, cb0, cb1, cb2, keep, res);
-                        kfw -= sKfw;
+                        for (int k = (NMPC_PROF_SKIP & 2) ? -1 : N - 1; k >= 0; k -= 2) {
+                            tv -= sTopV; dg -= sDgV; ab -= ST;
+                            w.bwd_stage(da, db, tv, dg, ab, kfw, cb0, cb1, cb2, keep, res);
+                            kfw -= sKfw;
+                            if (k == 0) break;
+                            tv -= sTopV; dg -= sDgV; ab -= ST;
+                            w.bwd_stage(db, da, tv, dg, ab, kfw, cb0, cb1, cb2, keep, res);
+                            kfw -= sKfw;
+                        }
+                    } else {
+                        w.bwd_fetch2(tv, dg, ab, ab2, da);
+#pragma unroll 1
+                        for (int k = (NMPC_PROF_SKIP & 2) ? -1 : N - 1; k >= 0; k -= 2) {
+                            tv -= sTopV; dg -= sDgV; ab -= ST; ab2 -= ST;
+                            w.bwd_stage2(da, db, tv, dg, ab, ab2, kfw, cb0, cb1, cb2, keep, res);
+                            kfw -= sKfw;
+                            if (k == 0) break;
+                            tv -= sTopV; dg -= sDgV; ab -= ST; ab2 -= ST;
+                            w.bwd_stage2(db, da, tv, dg, ab, ab2, kfw, cb0, cb1, cb2, keep, res);
+                            kfw -= sKfw;
+                        }
                     }
                     w.sweep_drain();
                     w.wsync();
@@ -728,7 +803,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     // start value: r_b (affine pass only) or kff
                     const double *p2;
                     int s2;
-                    if (vl >= 6) { p2 = stg + O_KFF + (vl - 6); s2 = ST; }
+                    if (vl >= 6) { p2 = stg + (vl == 6 ? L::KFF0 : L::KFF1); s2 = ST; }
                     else if (pass == 0) { p2 = stg + O_D + (vl < 3 ? vl : vl + 1); s2 = ST; }
                     else { p2 = stg + O_D + 4; s2 = ST; }     // the zero next to the corrector rhs (see E-B)
                     double *sw = xa + X_DUM;          // dx_{k+1}[r] -> slot k, du_k[a] -> slot k-1
@@ -879,8 +954,8 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
         // stage data of THIS linearisation still in LDS
         if (act) {
             double *sl = stg + tid * ST + O_D;
-            st2(sl - O_D + O_E, ll[0], ll[1]); st2(sl - O_D + O_E + 2, ll[2], ll[3]);       // bound multipliers
-            st2(sl - O_D + O_E + 4, lu[0], lu[1]); st2(sl - O_D + O_E + 6, lu[2], lu[3]);
+            st2(sl - O_D + L::LAM0, ll[0], ll[1]); st2(sl - O_D + L::LAM1, ll[2], ll[3]);       // bound multipliers
+            st2(sl - O_D + L::LAM2, lu[0], lu[1]); st2(sl - O_D + L::LAM3, lu[2], lu[3]);
             st2(sl + 0, Q00 * z[2] + Q01 * z[3] + Q02 * z[4] + g[2], Q01 * z[2] + Q11 * z[3] + g[3]);
             st2(sl + 2, Q02 * z[2] + Q22 * z[4] + g[4], Q33 * z[5] + g[5]);
             st2(sl + 4, Q44 * z[6] + g[6] - ll[2] + lu[2], Q55 * z[7] + g[7] - ll[3] + lu[3]);

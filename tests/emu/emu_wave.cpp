@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #define NMPC_DEV inline
@@ -81,9 +82,10 @@ void barrier(Barrier &b, int nthreads, int t)
     } while (b.gen == gen);
 }
 
-template <bool SQP, bool TWO = false>
+template <bool SQP, bool TWO = false, bool COMPACT = false>
 struct EmuWave {
-    static constexpr bool kSqp = SQP;   // same four instantiations as the GPU policy
+    using Layout = typename std::conditional<COMPACT, nmpcw::Layout48, nmpcw::Layout54>::type;
+    static constexpr bool kSqp = SQP;   // same six instantiations as the GPU policy
     static constexpr bool kNeighbourLds = TWO;
     int tid_;
     int tid() const { return tid_; }
@@ -145,6 +147,32 @@ struct EmuWave {
         res = fmac_row<1>(res, hc, cur[5]);
         *kfw = res;
     }
+    void bwd_fetch2(const double *tv, const double *dg, const double *ab, const double *ab2, double (&d)[6])
+    {
+        d[0] = tv[0]; d[1] = tv[1]; d[2] = tv[2];
+        d[3] = *dg;
+        d[4] = ab[0]; d[5] = ab2[0];
+    }
+    void bwd_stage2(double (&cur)[6], double (&nxt)[6], const double *tv, const double *dg, const double *ab,
+                    const double *ab2, double *kfw, double cb0, double cb1, double cb2, double keep, double &res)
+    {
+        double nx[6];
+        bwd_fetch2(tv, dg, ab, ab2, nx);
+        const double g0 = cur[3];
+        cur[3] = -1e300 * 1e10;     // consumed, as on the GPU
+        double hA = fmac_row<2>(g0, res, cur[0]);
+        double hB = fmac_row<3>(0.0, res, cur[1]);
+        hA = fmac_row<4>(hA, res, cur[2]);
+        hB = fmac_row<5>(hB, res, cb0);
+        hA = fmac_row<6>(hA, res, cb1);
+        hB = fmac_row<7>(hB, res, cb2);
+        const double hc = hA + hB;
+        res = keep * hc;
+        res = fmac_row<0>(res, hc, cur[4]);
+        res = fmac_row<1>(res, hc, cur[5]);
+        *kfw = res;
+        for (int i = 0; i < 6; ++i) nxt[i] = nx[i];
+    }
     template <int C>
     double fmac_row(double acc, double src, double coef)   // lane C of the caller's 16-lane row
     {
@@ -202,7 +230,14 @@ struct EmuWave {
 void thread_main(int t)
 {
     const bool two = g_s->nt > WAVE;
-    if (g_s->sqp && two) {
+    const bool compact = nmpcw::compact_layout(g_s->pb->N);      // the rule nmpc_solve launches by
+    if (g_s->sqp && two && compact) {
+        EmuWave<true, true, true> w{t};
+        nmpcw::solve_instance(w, *g_s->pb, *g_s->io);
+    } else if (two && compact) {
+        EmuWave<false, true, true> w{t};
+        nmpcw::solve_instance(w, *g_s->pb, *g_s->io);
+    } else if (g_s->sqp && two) {
         EmuWave<true, true> w{t};
         nmpcw::solve_instance(w, *g_s->pb, *g_s->io);
     } else if (g_s->sqp) {

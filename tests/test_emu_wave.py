@@ -85,10 +85,11 @@ def test_emulated_wave_sqp_mode_converges_to_the_oracle_fixed_point(N, B, gen):
         assert abs(g["cost"][i] - st.cost) <= 1e-9 * max(1.0, abs(st.cost))
 
 
-def test_emulated_wave_sqp_mode_iteration_limit():
+@pytest.mark.parametrize("N,B", [(20, 2), (100, 1)])
+def test_emulated_wave_sqp_mode_iteration_limit(N, B):
     """Status 2 (acados: maximum iterations) after exactly max_iter QPs when the KKT test still
-    fails; the iterate equals the oracle's after the same number of full steps."""
-    N, B = 20, 2
+    fails; the iterate equals the oracle's after the same number of full steps.  N = 100: two waves
+    and the 48-double stage layout (nmpcw::compact_layout), multipliers and costates through LDS."""
     cfg = orc.default_config(N, 0.35)
     x0, p = sc.config2(B)
     g = emu.solve_batch(cfg, x0, p, sqp_max_iter=2, sqp_tol=1e-12)

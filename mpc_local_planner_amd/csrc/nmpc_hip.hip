@@ -612,11 +612,13 @@ static int launch_solve(KernelArgs &a, int mode, hipStream_t stream, const int *
     // (two waves: the 48-double stage where it lets one more instance reside per CU, nmpcw::compact_layout)
     const bool compact = nmpcw::compact_layout(N);
     if (mode == NMPC_MODE_RTI) {
-        if (one) hipLaunchKernelGGL((nmpc_solve_kernel<1, false>), dim3(B), dim3(64), lds_bytes, stream, a);
+        if (one && compact) hipLaunchKernelGGL((nmpc_solve_kernel<1, false, true>), dim3(B), dim3(64), lds_bytes, stream, a);
+        else if (one) hipLaunchKernelGGL((nmpc_solve_kernel<1, false>), dim3(B), dim3(64), lds_bytes, stream, a);
         else if (compact) hipLaunchKernelGGL((nmpc_solve_kernel<2, false, true>), dim3(B), dim3(128), lds_bytes, stream, a);
         else hipLaunchKernelGGL((nmpc_solve_kernel<2, false>), dim3(B), dim3(128), lds_bytes, stream, a);
     } else {
-        if (one) hipLaunchKernelGGL((nmpc_solve_kernel<1, true>), dim3(B), dim3(64), lds_bytes, stream, a);
+        if (one && compact) hipLaunchKernelGGL((nmpc_solve_kernel<1, true, true>), dim3(B), dim3(64), lds_bytes, stream, a);
+        else if (one) hipLaunchKernelGGL((nmpc_solve_kernel<1, true>), dim3(B), dim3(64), lds_bytes, stream, a);
         else if (compact) hipLaunchKernelGGL((nmpc_solve_kernel<2, true, true>), dim3(B), dim3(128), lds_bytes, stream, a);
         else hipLaunchKernelGGL((nmpc_solve_kernel<2, true>), dim3(B), dim3(128), lds_bytes, stream, a);
     }
@@ -635,10 +637,10 @@ static int raise_lds_limit(int N)
     const int lds_bytes = nmpcw::lds_doubles(N) * (int)sizeof(double);
     if (lds_bytes <= 48 * 1024) return NMPC_OK;
     const bool one = nmpcw::waves_per_instance(N) == 1, compact = nmpcw::compact_layout(N);
-    const void *fns[2] = {one ? (const void *)nmpc_solve_kernel<1, false>
-                              : compact ? (const void *)nmpc_solve_kernel<2, false, true> : (const void *)nmpc_solve_kernel<2, false>,
-                          one ? (const void *)nmpc_solve_kernel<1, true>
-                              : compact ? (const void *)nmpc_solve_kernel<2, true, true> : (const void *)nmpc_solve_kernel<2, true>};
+    const void *fns[2] = {one ? (compact ? (const void *)nmpc_solve_kernel<1, false, true> : (const void *)nmpc_solve_kernel<1, false>)
+                              : (compact ? (const void *)nmpc_solve_kernel<2, false, true> : (const void *)nmpc_solve_kernel<2, false>),
+                          one ? (compact ? (const void *)nmpc_solve_kernel<1, true, true> : (const void *)nmpc_solve_kernel<1, true>)
+                              : (compact ? (const void *)nmpc_solve_kernel<2, true, true> : (const void *)nmpc_solve_kernel<2, true>)};
     for (const void *fn : fns)
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     return NMPC_OK;

@@ -102,9 +102,10 @@ constexpr int O_INV1 = 52;
 // input view of the factor sweep, overlaying the gain/inverse slots it writes afterwards
 constexpr int I_GAM01 = 12, I_GAM23 = 18, I_Q0 = 24, I_Q2 = 30;   // (gam0,gam1) (gam2,gam3) (Q00,Q01) (Q02,-)
 constexpr int I_G = 36;         // G[8]
-// The constants above are the 54-double stage (Layout54), used by every one-wave kernel.  Two-wave
-// instances whose LDS image would otherwise cost a resident instance per CU (N = 91..100: three instead
-// of four, N = 121..127: two instead of three) use the 48-double stage (Layout48): the same six column
+// The constants above are the 54-double stage (Layout54).  Horizons at which its LDS image costs a
+// resident instance per CU (compact_layout below: N = 91..102, three two-wave instances instead of four;
+// N = 122..127, two instead of three; N = 50..55 and 59..63, six / five one-wave instances instead of
+// seven / six) use the 48-double stage (Layout48): the same six column
 // groups, but kff and the rows of -inv(Huu) live in the groups' spare slots (single doubles, six apart)
 // and the gradient of the factor input is split between the O_E pairs and four spare slots.  Its stride
 // of 96 dwords puts every other stage on the same banks (4-way conflicts on the stage-layout accesses);
@@ -146,16 +147,21 @@ constexpr int X_SIZE = 168;
 constexpr int X_POLICY = 8;
 constexpr int waves_per_instance(int N) { return N + 1 <= 64 ? 1 : 2; }
 constexpr int lds_doubles_st(int st, int N) { return (N + 1) * st + X_SIZE + (waves_per_instance(N) > 1 ? X_POLICY : 0); }
-// instances of a two-wave kernel that fit into a CU: 160 KB of LDS (allocated in 512-byte steps), 8 waves at 256 VGPRs
-constexpr int two_wave_instances_per_cu(int st, int N)
+// instances that fit into a CU: 160 KB of LDS (allocated in 512-byte steps), 8 waves at up to 256 VGPRs
+constexpr int instances_per_cu(int st, int N)
 {
     const int bytes = (lds_doubles_st(st, N) * 8 + 511) / 512 * 512;
-    return 160 * 1024 / bytes < 4 ? 160 * 1024 / bytes : 4;
+    const int cap = 8 / waves_per_instance(N);
+    return 160 * 1024 / bytes < cap ? 160 * 1024 / bytes : cap;
 }
 // the 48-double stage where (and only where) it lets one more instance reside per CU
+// ... and where that pays: a one-wave kernel gains nothing from an eighth instance per CU (measured at
+// N = 44..48: 0.99-1.00x; 7 -> 8 waves only adds contention), 2-3 % from a seventh (N = 50..55), 6.5 % from
+// a sixth (N = 59..63); two-wave kernels gain 16-30 % (profiles/r2/long_horizon_probe_compact_layout.txt)
 constexpr bool compact_layout(int N)
 {
-    return waves_per_instance(N) > 1 && two_wave_instances_per_cu(Layout48::ST, N) > two_wave_instances_per_cu(Layout54::ST, N);
+    const int a = instances_per_cu(Layout54::ST, N), b = instances_per_cu(Layout48::ST, N);
+    return b > a && (waves_per_instance(N) > 1 || a < 7);
 }
 constexpr int lds_doubles(int N) { return lds_doubles_st(compact_layout(N) ? Layout48::ST : Layout54::ST, N); }
 

@@ -237,6 +237,12 @@ void thread_main(int t)
     } else if (two && compact) {
         EmuWave<false, true, true> w{t};
         nmpcw::solve_instance(w, *g_s->pb, *g_s->io);
+    } else if (g_s->sqp && compact) {
+        EmuWave<true, false, true> w{t};
+        nmpcw::solve_instance(w, *g_s->pb, *g_s->io);
+    } else if (compact) {
+        EmuWave<false, false, true> w{t};
+        nmpcw::solve_instance(w, *g_s->pb, *g_s->io);
     } else if (g_s->sqp && two) {
         EmuWave<true, true> w{t};
         nmpcw::solve_instance(w, *g_s->pb, *g_s->io);

@@ -19,7 +19,8 @@ def _err(g, xo, uo):
 @pytest.mark.parametrize("N,gen,kernel", [(40, sc.config2, "quad"), (10, sc.config2, "quad"), (63, sc.config2, "quad"),
                                           (1, sc.config2, "quad"), (2, sc.config2, "quad"), (40, sc.config4, "quad"),
                                           (40, sc.config2, "wave"), (1, sc.config2, "wave"),
-                                          (40, sc.config4, "wave"), (64, sc.config2, "wave"), (100, sc.config4, "wave")])
+                                          (40, sc.config4, "wave"), (64, sc.config2, "wave"), (100, sc.config4, "wave"),
+                                          (63, sc.config2, "wave"), (50, sc.config4, "wave")])
 def test_emulated_wave_matches_oracle_cold_and_warm(N, gen, kernel):
     """Both solve kernels: "quad" = four instances per workgroup (SQP-RTI up to N = 63, what nmpc_solve
     launches there), "wave" = one instance per workgroup (SQP mode and longer horizons)."""

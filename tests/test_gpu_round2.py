@@ -486,3 +486,64 @@ def test_stalled_interior_point_iterations_fail_early():
     assert np.array_equal(st_on == 4, failed)                  # the same instances fail, ...
     assert (it_on[failed] == 20).all()                         # ... thirty iterations earlier
     assert np.array_equal(it_on[~failed], it_off[~failed])     # nothing else changes
+
+
+def test_every_horizon_matches_the_oracle():
+    """All horizons 1..127 -- across the one-wave / two-wave boundary and every switch between the 54- and
+    the 48-double stage layout (nmpcw::compact_layout: 49|50, 55|56, 58|59, 63|64, 90|91, 102|103,
+    121|122) -- cold call and one warm call (re-seeded from the oracle's iterate, as in
+    test_cold_then_warm_rti_matches_oracle), four instances each, against the oracle."""
+    B = 4
+    x0, p = sc.config2(B, start=900)
+    x1, p1 = sc.config2(B, start=904)
+    xw, pw = x0 + 0.05 * (x1 - x0), p + 0.05 * (p1 - p)
+    worst = 0.0
+    for N in range(1, 128):
+        s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
+        s.set_x0(x0)
+        s.set_params(p)
+        s.solve(B)
+        g = s.get(B)
+        ocfg = _ocfg(N)
+        xo, uo, so, io = orc.rti_batch(ocfg, x0, p)
+        assert np.array_equal(g["status"], so), N
+        ok = so == 0
+        e = (_err(g, xo, uo) / _scale(xo, uo))[ok]
+        assert (e <= TOL_BAR).all(), (N, e.max())
+        assert (np.abs(g["ipm_iters"] - io) <= 1).all(), N
+        worst = max(worst, e.max() if e.size else 0.0)
+        # warm call on a moved measurement, both sides from the oracle's iterate
+        s.set_iterate(xo, uo)
+        s.set_x0(xw)
+        s.set_params(pw)
+        s.solve(B)
+        g = s.get(B)
+        xo2, uo2, so2, _ = orc.rti_batch(ocfg, xw, pw, xo.copy(), uo.copy(), cold=False)
+        assert np.array_equal(g["status"], so2), N
+        ok = so2 == 0
+        e = (_err(g, xo2, uo2) / _scale(xo2, uo2))[ok]
+        assert (e <= TOL_BAR).all(), (N, "warm", e.max())
+        s.close()
+    assert worst <= TOL_BAR
+
+
+@pytest.mark.parametrize("N", [50, 58, 59, 63, 64, 90, 91, 102, 103, 121, 122])
+def test_sqp_mode_at_the_layout_boundaries(N):
+    """SQP mode (multipliers and costates wait in the LDS image between QPs) on either side of every
+    layout switch: same status, same number of QPs and the same iterate as the oracle after three QPs."""
+    B = 6
+    x0, p = sc.config2(B, start=40)
+    s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
+    s.set_x0(x0)
+    s.set_params(p)
+    s.solve(B, mode=capi.MODE_SQP, max_iter=3, tol=1e-13)
+    g = s.get(B)
+    s.close()
+    ocfg = _ocfg(N)
+    for i in range(B):
+        xo, uo = orc.init_guess(ocfg, x0[i])
+        st = orc.sqp(ocfg, x0[i], p[i], xo, uo, 3, 1e-13)
+        assert g["status"][i] == st.status and g["sqp_iters"][i] == st.sqp_iters, (N, i)
+        if st.status in (0, 2):
+            sc_ = max(1.0, np.abs(xo).max(), np.abs(uo).max())
+            assert np.abs(g["x"][i] - xo).max() <= TOL_BAR * sc_ and np.abs(g["u"][i] - uo).max() <= TOL_BAR * sc_, (N, i)

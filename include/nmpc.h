@@ -213,6 +213,13 @@ int nmpc_solve_static(const nmpc_config *cfg, int device, void *stream, int B, i
  * nmpc_set_controls_device and run the collective on a second stream. */
 int nmpc_gather_controls(nmpc_handle *h, void *nccl_comm, int B, double *d_all);
 
+/* Which instances of a fleet of `total` rank `rank` of `world` owns: the contiguous block
+ * [*begin, *begin + *count); blocks differ by at most one instance, lower ranks take the remainder.
+ * Host-only arithmetic (no GPU call), the same rule as mpc_local_planner_amd/sharding.py::shard_range,
+ * so that C++ and Python callers cut a fleet the same way.  No reference counterpart (one solver there,
+ * src/PathTrackingSys.cpp:58-61).  NMPC_EINVAL for a rank outside [0, world) or a negative total. */
+int nmpc_shard_range(int64_t total, int rank, int world, int64_t *begin, int64_t *count);
+
 /* Device-side views for zero-copy consumers (RCCL all-gather of the control records,
  * timing with HIP events).  which: 0 control records [cap][6], 1 iterate [cap][N+1][8]
  * (X,Y,psi,v,delta,thr,u0,u1 per node), 2 status int32[cap]. */

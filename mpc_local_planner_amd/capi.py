@@ -38,7 +38,7 @@ EXPORTS = [
     "nmpc_set_inputs_device", "nmpc_set_weights", "nmpc_set_bounds", "nmpc_set_horizons", "nmpc_reset", "nmpc_set_iterate",
     "nmpc_solve", "nmpc_solve_static",
     "nmpc_sync", "nmpc_get", "nmpc_get_controls", "nmpc_device_ptr", "nmpc_stream", "nmpc_set_controls_device",
-    "nmpc_capacity", "nmpc_horizon", "nmpc_last_error", "nmpc_gather_controls",
+    "nmpc_capacity", "nmpc_horizon", "nmpc_last_error", "nmpc_gather_controls", "nmpc_shard_range",
     "nmpc_set_track", "nmpc_frontend", "nmpc_get_frontend", "nmpc_get_world_path", "nmpc_closed_loop",
 ]
 
@@ -81,6 +81,7 @@ def lib():
     l.nmpc_device_ptr.restype = vp
     l.nmpc_set_controls_device.argtypes = [vp, vp]
     l.nmpc_gather_controls.argtypes = [vp, vp, C.c_int, vp]
+    l.nmpc_shard_range.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     l.nmpc_stream.argtypes = [vp]
     l.nmpc_stream.restype = vp
     l.nmpc_capacity.argtypes = [vp]

@@ -1136,6 +1136,15 @@ int nmpc_solve_static(const nmpc_config *cfg, int device, void *stream, int B, i
     return launch_solve(a, NMPC_MODE_RTI, st, cold ? nullptr : sc->hist, sc->order, kernel_choice());
 }
 
+int nmpc_shard_range(int64_t total, int rank, int world, int64_t *begin, int64_t *count)
+{
+    if (!begin || !count || world <= 0 || rank < 0 || rank >= world || total < 0) return NMPC_EINVAL;
+    const int64_t base = total / world, rem = total % world;
+    *begin = rank * base + (rank < rem ? rank : rem);
+    *count = base + (rank < rem ? 1 : 0);
+    return NMPC_OK;
+}
+
 int nmpc_sync(nmpc_handle *h)
 {
     if (!h) return NMPC_EINVAL;

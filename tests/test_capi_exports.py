@@ -51,6 +51,26 @@ def test_config_struct_matches_header_layout(built_lib):
     assert cfg.ipm_tol_comp == 1e-11 and cfg.ipm_max_iter == 50
 
 
+def test_shard_range_matches_the_python_rule(built_lib):
+    """nmpc_shard_range (host-only) cuts a fleet exactly as sharding.shard_range does; blocks tile the fleet."""
+    import ctypes as C
+    from mpc_local_planner_amd import capi, sharding
+    l = capi.lib()
+    for total in (0, 1, 7, 4096, 1_000_003, 2**33 + 5):
+        for world in (1, 2, 3, 8):
+            end = 0
+            for rank in range(world):
+                b, c = C.c_int64(), C.c_int64()
+                assert l.nmpc_shard_range(total, rank, world, C.byref(b), C.byref(c)) == capi.OK
+                assert (b.value, b.value + c.value) == sharding.shard_range(rank, world, total)
+                assert b.value == end
+                end = b.value + c.value
+            assert end == total
+    b, c = C.c_int64(), C.c_int64()
+    assert l.nmpc_shard_range(10, 2, 2, C.byref(b), C.byref(c)) == capi.EINVAL
+    assert l.nmpc_shard_range(-1, 0, 2, C.byref(b), C.byref(c)) == capi.EINVAL
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under mpc_local_planner_amd/ may import, include
     or link it (and there is no CPU fallback: capi.lib() raises when the HIP library is missing)."""

@@ -95,3 +95,15 @@ def test_cpp_mirror_single_and_batch(tmp_path):
         s = max(1.0, np.abs(x1).max())
         assert np.abs(single[call][:, :6] - x1[0, :N]).max() <= 1e-6 * s, call
         assert np.abs(single[call][:, 6:] - u1[0]).max() <= 1e-6 * s, call
+
+
+def test_cpp_multi_gpu_example_single_rank():
+    """examples/multi_gpu_gather.cpp (the recipe of INTEGRATION.md section 4: nmpc_shard_range, one solve,
+    nmpc_gather_controls through a real RCCL communicator) with one rank: the gathered block equals the
+    local records and every record is a successful solve."""
+    exe = os.path.join(ROOT, "examples", "multi_gpu_gather")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    env = dict(os.environ, NMPC_RANK="0", NMPC_WORLD="1")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=110, env=env)
+    assert out.returncode == 0, (out.returncode, out.stdout[-1000:], out.stderr[-2000:])
+    assert "rank 0 of 1: vehicles [0, 4096), 4096 records gathered, 0 not ok" in out.stdout

@@ -557,9 +557,9 @@ static void fill_problem(const nmpc_config &c, int mode, int max_iter, double to
 
 // Which solve kernel.  Two implement SQP-RTI up to N = 63: one instance per workgroup
 // (nmpc_wave_solver.h) and four slots per workgroup fed from a ticket queue (nmpc_quad_solver.h).
-// Measured (gpurun_out -> profiles/r2/quad_vs_wave.md): the four-slot kernel is 3-7 % faster where two
+// Measured (gpurun_out -> profiles/r2/quad_vs_wave.md): the four-slot kernel is 1-8 % faster where two
 // of its workgroups fit into a CU's LDS (N <= 43) and the sweeps are long enough to pay for its four
-// workgroup barriers per iteration (N >= 28), once the batch fills the chip several times over; it is
+// workgroup barriers per iteration (N >= 32), once the batch fills the chip several times over; it is
 // slower for short horizons, by 25 % where only one workgroup fits, and has the longer single-solve
 // latency.  NMPC_KERNEL=quad / wave forces one of them (read when a handle is created / per call of
 // nmpc_solve_static); everything else -- SQP mode, N > 63, per-instance horizons -- runs on the
@@ -576,7 +576,7 @@ static bool use_quad_kernel(KernelChoice c, int mode, int N, int B)
     if (mode != NMPC_MODE_RTI || nmpcw::waves_per_instance(N) != 1 || c == KERNEL_WAVE) return false;
     if (c == KERNEL_QUAD) return true;
     const size_t qbytes = (size_t)nmpcq::quad_lds_doubles(N) * sizeof(double);
-    return B >= 8192 && N >= 28 && 2 * qbytes <= 160 * 1024;
+    return B >= 8192 && N >= 32 && 2 * qbytes <= 160 * 1024;
 }
 
 // Order kernel (optional: `hist` = iteration counts of the previous solve, `order` = its output) and

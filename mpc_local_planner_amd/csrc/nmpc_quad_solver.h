@@ -34,7 +34,7 @@
 // not the factor the counters suggest: LDS capacity (19 KB per instance at N = 40) and 256 VGPRs per slot
 // wave both stop at eight instances per CU, so a CU runs two sweep streams where the other kernel runs
 // eight waves, and an interior-point iteration of a workgroup (~24-30 us) costs what it costs there.
-// nmpc_solve picks it where it wins: 28 <= N <= 43 (two workgroups per CU) and batches of 8192 and more
+// nmpc_solve picks it where it wins: 32 <= N <= 43 (two workgroups per CU) and batches of 8192 and more
 // (nmpc_hip.hip: use_quad_kernel; NMPC_KERNEL=quad / wave forces a kernel).
 #pragma once
 
@@ -45,6 +45,9 @@ namespace nmpcq {
 using namespace nmpcw;
 
 constexpr int QI = 4;            // instances per workgroup = 16-lane rows per wave
+#ifndef NMPC_QUAD_SYM
+#define NMPC_QUAD_SYM 8          // the cost-to-go is symmetrised every so many stages of the factor sweep (even)
+#endif
 // per-stage constants of the factor sweep in the spare slot (offset 5) of the column groups, so that
 // every lane of every start-value load walks the stages with the same stride
 constexpr int S_Q11 = 0 * GS + 5, S_Q22 = 1 * GS + 5, S_Q33 = 2 * GS + 5, S_ZERO = 3 * GS + 5, S_ONE = 4 * GS + 5;
@@ -433,6 +436,30 @@ NMPC_DEV void solve_quad(W &w, const Problem &pb, const Batch &bt)
                         ka -= sK;
 #pragma unroll
                         for (int i = 0; i < 8; ++i) ha[i] -= 2 * ST;
+                        // Rows of the cost-to-go are formed independently of each other, so round-off makes
+                        // it slightly unsymmetric, and the unsymmetric part is not damped by the recursion:
+                        // it is carried from stage to stage by the open-loop dynamics, P_a <- A' P_a A, and
+                        // on ill-conditioned stage costs (path curvature of the order of 100) grew to 1e-4
+                        // of the gains over 40 stages (found by tools/stress_parity.py; the one-instance
+                        // kernel forms only the upper triangle and mirrors it).  Every NMPC_QUAD_SYM stages
+                        // the 6x6 block is therefore replaced by its symmetric part, through the (otherwise
+                        // unused) cost-to-go slots of the exchange area.
+                        if ((((N - 1 - k) >> 1) % (NMPC_QUAD_SYM / 2)) == NMPC_QUAD_SYM / 2 - 1) {
+                            double *sp = rxa + X_P;
+                            const bool in = j >= 2 && j < 8;
+                            const int jj = in ? j - 2 : 0;
+                            if (in) {
+#pragma unroll
+                                for (int i = 0; i < 6; ++i) sp[i * 8 + jj] = RA[i + 2];
+                            }
+                            w.wsync();
+#pragma unroll
+                            for (int i = 0; i < 6; ++i) {
+                                const double t = sp[jj * 8 + i];
+                                RA[i + 2] = in ? 0.5 * (RA[i + 2] + t) : RA[i + 2];
+                            }
+                            w.wsync();
+                        }
                     }
                     w.sweep_drain();
                     w.wsync();

@@ -431,6 +431,10 @@ extern "C" int emu_solve_batch(int N, double dt, double wheelbase, int ipm_max_i
         for (int t = 0; t < s.nt; ++t)
             if (!s.done[t]) { fprintf(stderr, "emu: thread %d did not finish\n", t); rc = 1; }
     }
+    if (const char *f = getenv("EMU_DUMP_LDS")) {      // debugging aid: the LDS image after the last instance
+        FILE *fp = fopen(f, "wb");
+        if (fp) { fwrite(s.lds, sizeof(double), (size_t)nmpcw::lds_doubles(N), fp); fclose(fp); }
+    }
     g_s = nullptr;
     return rc;
 }
@@ -491,6 +495,14 @@ extern "C" int emu_solve_batch_quad(int N, double dt, double wheelbase, int ipm_
         for (int t = 0; t < s.nt; ++t)
             if (!s.done[t]) { fprintf(stderr, "emu(quad): thread %d did not finish\n", t); rc = 1; }
         if (queue < B) { fprintf(stderr, "emu(quad): workgroup ended with %d of %d tickets drawn\n", queue, B); rc = 1; }
+        if (const char *f = getenv("EMU_DUMP_LDS")) {  // debugging aid: the LDS image of the first workgroup at its end
+            static int dumped_for = -1;
+            if (dumped_for != queue || true) {
+                FILE *fp = fopen(f, "ab");
+                if (fp) { fwrite(s.lds, sizeof(double), nl, fp); fclose(fp); }
+            }
+            dumped_for = queue;
+        }
     }
     g_s = nullptr;
     return rc;

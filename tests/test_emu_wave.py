@@ -123,3 +123,25 @@ def test_emulated_wave_failure_paths_match_the_oracle(kernel):
     xo, uo, so, io = orc.rti_batch(cfg3, x0, p)
     assert (g["status"] == 4).all() and (so == 4).all() and (g["ipm_iters"] == 3).all()
     assert _err(g, xo, uo).max() <= 1e-9
+
+
+@pytest.mark.parametrize("kernel", ["quad", "wave"])
+def test_emulated_kernels_on_an_ill_conditioned_stage_cost(kernel):
+    """A path polynomial with curvature coefficient c2 = 170 (found by tools/stress_parity.py: 1 % of an
+    extreme neighbour mixed into the parameters) makes the stage costs ill-conditioned.  The four-slot
+    kernel forms the rows of the cost-to-go independently; without symmetrising it every few stages the
+    unsymmetric round-off grew along the factor sweep until the QP 'converged' 7e-2 away from the solution
+    (36 interior-point iterations instead of 15 at N = 63).  Both kernels must stay at the oracle's result."""
+    xa, pa = sc.config2(2, start=20_000_000 + 16767)
+    x1 = (xa[1] + 0.01 * (xa[0] - xa[1]))[None]
+    p1 = (pa[1] + 0.01 * (pa[0] - pa[1]))[None]
+    assert 150.0 < p1[0, 2] < 200.0
+    for N in (40, 63):
+        cfg = orc.default_config(N, 0.35)
+        xo, uo, so, _ = orc.rti_batch(cfg, xa[1:2], pa[1:2])
+        xo2, uo2, so2, io2 = orc.rti_batch(cfg, x1, p1, xo.copy(), uo.copy(), cold=False)
+        assert so2[0] == 0
+        traj = np.zeros((1, N + 1, 8)); traj[:, :, :6] = xo; traj[:, :N, 6:] = uo
+        g = emu.solve_batch(cfg, x1, p1, traj=traj, cold=False, kernel=kernel)
+        assert g["status"][0] == 0 and abs(int(g["ipm_iters"][0]) - int(io2[0])) <= 1
+        assert _err(g, xo2, uo2).max() <= 1e-7 * max(1.0, np.abs(xo2).max())

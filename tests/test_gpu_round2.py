@@ -290,7 +290,7 @@ def test_quad_kernel_full_batch_and_weights(monkeypatch):
 
 
 def test_kernel_choice_by_batch_and_horizon(monkeypatch):
-    """Without NMPC_KERNEL the library picks the four-slot kernel for 28 <= N <= 43 and B >= 8192 and the
+    """Without NMPC_KERNEL the library picks the four-slot kernel for 32 <= N <= 43 and B >= 8192 and the
     one-instance kernel otherwise (nmpc_hip.hip: use_quad_kernel).  Seen from outside: the automatic
     choice is bit-identical to the forced kernel it should have picked, and both kernels agree to the bar."""
     def run(N, B, kern):
@@ -547,3 +547,32 @@ def test_sqp_mode_at_the_layout_boundaries(N):
         if st.status in (0, 2):
             sc_ = max(1.0, np.abs(xo).max(), np.abs(uo).max())
             assert np.abs(g["x"][i] - xo).max() <= TOL_BAR * sc_ and np.abs(g["u"][i] - uo).max() <= TOL_BAR * sc_, (N, i)
+
+
+@pytest.mark.parametrize("kern", ["quad", "wave"])
+def test_ill_conditioned_stage_costs_both_kernels(kern, monkeypatch):
+    """GPU counterpart of tests/test_emu_wave.py::test_emulated_kernels_on_an_ill_conditioned_stage_cost,
+    on a whole neighbourhood of the stress batch (warm call, 1 % of the neighbour mixed into every
+    instance's inputs: path curvature coefficients up to the hundreds): every instance the oracle solves
+    stays within the bar, with the oracle's iteration count."""
+    monkeypatch.setenv("NMPC_KERNEL", kern)
+    B = 512
+    xa, pa = sc.config2(B + 1, start=20_000_000 + 16767 - 200)
+    x1 = xa[1:] + 0.01 * (xa[:-1] - xa[1:])
+    p1 = pa[1:] + 0.01 * (pa[:-1] - pa[1:])
+    for N in (40, 63):
+        ocfg = _ocfg(N)
+        xo, uo, so, _ = orc.rti_batch(ocfg, xa[1:], pa[1:])
+        xo2, uo2, so2, io2 = orc.rti_batch(ocfg, x1, p1, xo.copy(), uo.copy(), cold=False)
+        s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
+        s.set_iterate(xo, uo)
+        s.set_x0(x1)
+        s.set_params(p1)
+        s.solve(B)
+        g = s.get(B)
+        s.close()
+        ok = so2 == 0
+        assert ok.mean() > 0.99 and np.array_equal(g["status"][ok], so2[ok])
+        e = (_err(g, xo2, uo2) / _scale(xo2, uo2))[ok]
+        assert e.max() <= TOL_BAR, (N, kern, e.max())
+        assert (np.abs(g["ipm_iters"] - io2)[ok] <= 1).all()

@@ -10,8 +10,8 @@ import ctypes as C
 
 lib = bench._fast_oracle()[0] if hasattr(bench, "_fast_oracle") else None
 B = int(os.environ.get("STRESS_B", "20000"))
-for N in (40, 30, 63, 100):
-    for start in (10_000_000, 20_000_000):
+for N in [int(v) for v in os.environ.get("STRESS_N", "40,30,63,100").split(",")]:
+    for start in [int(v) for v in os.environ.get("STRESS_SEEDS", "10000000,20000000").split(",")]:
         x0, p = sc.config2(B, start=start) if N != 100 else sc.config4(B // 4, start=start)
         Bn = x0.shape[0]
         ocfg = orc.config_like(capi.default_config(N, 0.35))

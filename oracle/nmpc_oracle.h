@@ -50,6 +50,14 @@ typedef struct orc_config {
     double ipm_tol_comp; /* max_i min(t_i, lam_i): pairwise complementarity, see orc_qp_ipm */
     int ipm_stall_iter;  /* early failure (status 4): after this many iterations ... (0: never) */
     double ipm_stall_lin; /* ... the infeasibility scale is still above this */
+    /* active-set polish of the QP (see orc_ws_solve) */
+    int polish;           /* 0: interior point to the end; 1: finish on the identified active set */
+    double polish_mu;     /* first attempt once the average complementarity is below this */
+    int polish_tries;     /* primal-dual active-set corrections per attempt */
+    double polish_tol;    /* KKT tolerance of acceptance (multiplier signs, feasibility of dropped bounds) */
+    int warm_tries;       /* warm calls: corrections of the attempt on the iterate's own active set; < 0: never try it */
+    int warm_gate;        /* ... tried when the previous call moved at most this many pairs in or out of the set */
+    double warm_eps;      /* iterate within this of a bound = guessed active */
 } orc_config;
 
 /* fills cfg with the reference's defaults (N and dt given explicitly) */
@@ -97,6 +105,20 @@ typedef struct orc_qp {
 
 int orc_qp_ipm(const orc_config *cfg, const orc_qp *qp, double *dx, double *du, double *lam,
                double *pi, int *iters, double *mu_out);
+/* The equality-constrained QP on a working set, solved exactly by one Riccati recursion in which the pinned
+ * quantities are eliminated stage by stage (what the active-set polish of orc_qp_solve runs).
+ * ws[N*4]: per stage the pairs u0, u1, x4, x5: -1 at the lower bound lo[], +1 at the upper bound up[], 0 free
+ * (state pairs of stage 0 are ignored).  z[(N+1)*8] per node [dx(6); du(2)]: in z[0..5] = dx0, out the
+ * minimiser; sm[N*4]: signed multipliers of the pins (an upper bound wants >= 0, a lower <= 0).
+ * Returns 0, or -1 when a stage's pins are not independent (an input pinned together with the state of the
+ * next node it integrates into). */
+int orc_ws_solve(const orc_qp *qp, const double *lo, const double *up, const int *ws, double *z, double *sm);
+
+/* the same with the warm-start hint of a sequence of QPs (in/out, one double per instance that the caller
+   keeps between calls and zeroes on a cold start; NULL: none): 0 = nothing known, 1 + n = the previous QP
+   ended polished on an active set that differed from the one its iterate suggested in n pairs */
+int orc_qp_solve(const orc_config *cfg, const orc_qp *qp, double *hint, double *dx, double *du, double *lam,
+                 double *pi, int *iters, double *mu_out);
 
 typedef struct orc_stats {
     int status;       /* 0 ok, 1 NaN, 2 max iter (SQP), 4 QP failure */
@@ -111,10 +133,16 @@ typedef struct orc_stats {
    xtraj[(N+1)*6], utraj[N*2] in/out (warm start, no shift: PathTrackingSys.cpp:58-61) */
 int orc_rti(const orc_config *cfg, const double *x0, const double *p, double *xtraj,
             double *utraj, orc_stats *st);
+/* ... with the warm-start hint of orc_qp_solve carried from call to call (one double, zero it on a cold
+   start and after a failed call) */
+int orc_rti_h(const orc_config *cfg, const double *x0, const double *p, double *xtraj,
+              double *utraj, double *hint, orc_stats *st);
 
 /* full SQP: repeat until the NLP KKT residuals <= tol or max_iter */
 int orc_sqp(const orc_config *cfg, const double *x0, const double *p, double *xtraj, double *utraj,
             int max_iter, double tol, orc_stats *st);
+int orc_sqp_h(const orc_config *cfg, const double *x0, const double *p, double *xtraj, double *utraj,
+              int max_iter, double tol, double *hint, orc_stats *st);
 
 /* cold guess x_k = x0, u_k = 0 (AcadosSolver.cpp:78-92) */
 void orc_init_guess(const orc_config *cfg, const double *x0, double *xtraj, double *utraj);
@@ -126,6 +154,11 @@ void orc_rti_batch(const orc_config *cfg, int B, const double *x0, const double 
 /* one instance per OpenMP thread (serial without -fopenmp) */
 void orc_rti_batch_mt(const orc_config *cfg, int B, const double *x0, const double *p, double *xtraj,
                       double *utraj, int *status, int *ipm_iters, int cold, int nthreads);
+/* the same two with the per-instance warm-start hints hint[B] (cold != 0 zeroes them) */
+void orc_rti_batch_h(const orc_config *cfg, int B, const double *x0, const double *p, double *xtraj,
+                     double *utraj, double *hint, int *status, int *ipm_iters, int cold);
+void orc_rti_batch_mt_h(const orc_config *cfg, int B, const double *x0, const double *p, double *xtraj,
+                        double *utraj, double *hint, int *status, int *ipm_iters, int cold, int nthreads);
 
 /* ---- path front-end ---- */
 /* getTestTrack (utilities.cpp:59-72): returns number of points written (<= cap) */

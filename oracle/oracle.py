@@ -25,6 +25,8 @@ class Config(C.Structure):
         ("ipm_max_iter", C.c_int), ("ipm_mu0", C.c_double), ("ipm_thr0", C.c_double),
         ("ipm_tau", C.c_double), ("ipm_tol_mu", C.c_double), ("ipm_tol_lin", C.c_double),
         ("ipm_tol_comp", C.c_double), ("ipm_stall_iter", C.c_int), ("ipm_stall_lin", C.c_double),
+        ("polish", C.c_int), ("polish_mu", C.c_double), ("polish_tries", C.c_int), ("polish_tol", C.c_double),
+        ("warm_tries", C.c_int), ("warm_gate", C.c_int), ("warm_eps", C.c_double),
     ]
 
 
@@ -70,6 +72,15 @@ def lib():
         _lib.orc_qp_ipm.restype = C.c_int
         _lib.orc_rti.argtypes = [cp, dp, dp, dp, dp, C.POINTER(Stats)]
         _lib.orc_rti.restype = C.c_int
+        _lib.orc_rti_h.argtypes = [cp, dp, dp, dp, dp, dp, C.POINTER(Stats)]
+        _lib.orc_rti_h.restype = C.c_int
+        _lib.orc_sqp_h.argtypes = [cp, dp, dp, dp, dp, C.c_int, C.c_double, dp, C.POINTER(Stats)]
+        _lib.orc_sqp_h.restype = C.c_int
+        _lib.orc_qp_solve.argtypes = [cp, C.POINTER(QP), dp, dp, dp, dp, dp, ip, dp]
+        _lib.orc_qp_solve.restype = C.c_int
+        _lib.orc_ws_solve.argtypes = [C.POINTER(QP), dp, dp, ip, dp, dp]
+        _lib.orc_ws_solve.restype = C.c_int
+        _lib.orc_rti_batch_h.argtypes = [cp, C.c_int, dp, dp, dp, dp, dp, ip, ip, C.c_int]
         _lib.orc_sqp.argtypes = [cp, dp, dp, dp, dp, C.c_int, C.c_double, C.POINTER(Stats)]
         _lib.orc_sqp.restype = C.c_int
         _lib.orc_init_guess.argtypes = [cp, dp, dp, dp]
@@ -167,6 +178,21 @@ def qp_ipm(cfg, A, B, b, H, g, lu, uu, lx, ux, dx0):
     return dict(status=st, dx=dx, du=du, lam=lam, pi=pi, iters=it.value, mu=mu.value)
 
 
+def ws_solve(A, B, b, H, g, dx0, lo, up, ws):
+    """Equality-constrained QP on the working set ws[N,4] (-1 lower, +1 upper, 0 free; pairs u0,u1,x4,x5 with
+    bounds lo/up[N,4]); returns (rc, z[N+1,8] per node [dx;du], sm[N,4])."""
+    N = A.shape[0]
+    zer = np.zeros((N, 2))
+    arrs = [_f64(a) for a in (A, B, b, H, g, zer, zer, zer, zer, dx0)]
+    qp = QP(N, *[_dp(a) for a in arrs])
+    z = np.zeros((N + 1, 8)); z[0, :6] = dx0
+    sm = np.zeros((N, 4))
+    lo, up = _f64(lo), _f64(up)
+    ws = np.ascontiguousarray(ws, dtype=np.int32)
+    rc = lib().orc_ws_solve(C.byref(qp), _dp(lo), _dp(up), _ip(ws), _dp(z), _dp(sm))
+    return rc, z, sm
+
+
 def init_guess(cfg, x0):
     x0 = _f64(x0)
     xt, ut = np.zeros((cfg.N + 1, NX)), np.zeros((cfg.N, NU))
@@ -174,12 +200,14 @@ def init_guess(cfg, x0):
     return xt, ut
 
 
-def rti(cfg, x0, p, xtraj, utraj):
-    """In-place SQP-RTI step on (xtraj, utraj); returns Stats."""
+def rti(cfg, x0, p, xtraj, utraj, hint=None):
+    """In-place SQP-RTI step on (xtraj, utraj); returns Stats.  hint: one-element float64 array carried from
+    call to call of a warm sequence (zero it on a cold start), or None."""
     x0, p = _f64(x0), _f64(p)
     assert xtraj.flags.c_contiguous and utraj.flags.c_contiguous
     st = Stats()
-    lib().orc_rti(C.byref(cfg), _dp(x0), _dp(p), _dp(xtraj), _dp(utraj), C.byref(st))
+    lib().orc_rti_h(C.byref(cfg), _dp(x0), _dp(p), _dp(xtraj), _dp(utraj), _dp(hint) if hint is not None else None,
+                    C.byref(st))
     return st
 
 
@@ -190,7 +218,8 @@ def sqp(cfg, x0, p, xtraj, utraj, max_iter=20, tol=1e-6):
     return st
 
 
-def rti_batch(cfg, x0, p, xtraj=None, utraj=None, cold=True):
+def rti_batch(cfg, x0, p, xtraj=None, utraj=None, cold=True, hint=None):
+    """hint: float64[B] warm-start hints carried from call to call (updated in place), or None."""
     x0, p = _f64(x0), _f64(p)
     Bn = x0.shape[0]
     if xtraj is None:
@@ -198,8 +227,8 @@ def rti_batch(cfg, x0, p, xtraj=None, utraj=None, cold=True):
         utraj = np.zeros((Bn, cfg.N, NU))
     status = np.zeros(Bn, dtype=np.int32)
     iters = np.zeros(Bn, dtype=np.int32)
-    lib().orc_rti_batch(C.byref(cfg), Bn, _dp(x0), _dp(p), _dp(xtraj), _dp(utraj), _ip(status),
-                        _ip(iters), 1 if cold else 0)
+    lib().orc_rti_batch_h(C.byref(cfg), Bn, _dp(x0), _dp(p), _dp(xtraj), _dp(utraj),
+                          _dp(hint) if hint is not None else None, _ip(status), _ip(iters), 1 if cold else 0)
     return xtraj, utraj, status, iters
 
 

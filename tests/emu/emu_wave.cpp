@@ -383,7 +383,8 @@ extern "C" int emu_solve_batch(int N, double dt, double wheelbase, int ipm_max_i
                                int sqp_max_iter, double sqp_tol, int B, const double *x0,
                                const double *p, const double *W, const double *bnd, double *traj,
                                double *ctrl, int *status, int *iters, int *sqp_iters, double *cost,
-                               int cold, int stall_iter, double stall_lin)
+                               int cold, int stall_iter, double stall_lin, int polish, double polish_mu,
+                               int polish_tries, double polish_tol, int warm_tries, int warm_gate, double warm_eps)
 {
     // sqp_max_iter <= 0: one SQP-RTI iteration; > 0: SQP mode with that many iterations at most
     if (N < 1 || N > 127) return 2;
@@ -393,6 +394,8 @@ extern "C" int emu_solve_batch(int N, double dt, double wheelbase, int ipm_max_i
     pb.tol_mu = tol_mu; pb.tol_lin = tol_lin; pb.tol_comp = tol_comp;
     pb.sqp_max_iter = sqp_max_iter > 0 ? sqp_max_iter : 1; pb.sqp_tol = sqp_tol;
     pb.stall_iter = stall_iter; pb.stall_lin = stall_lin;
+    pb.polish = polish; pb.polish_mu = polish_mu; pb.polish_tries = polish_tries; pb.polish_tol = polish_tol;
+    pb.warm_tries = warm_tries; pb.warm_gate = warm_gate; pb.warm_eps = warm_eps;
     Sched s;
     g_s = &s;
     s.sqp = sqp_max_iter > 0;
@@ -455,6 +458,8 @@ extern "C" int emu_solve_batch_quad(int N, double dt, double wheelbase, int ipm_
     pb.tol_mu = tol_mu; pb.tol_lin = tol_lin; pb.tol_comp = tol_comp;
     pb.sqp_max_iter = 1; pb.sqp_tol = 0.0;
     pb.stall_iter = stall_iter; pb.stall_lin = stall_lin;
+    pb.polish = 0; pb.polish_mu = 0.0; pb.polish_tries = 0; pb.polish_tol = 0.0;     // (this solver is interior point only)
+    pb.warm_tries = -1; pb.warm_gate = 0; pb.warm_eps = 0.0;
     Sched s;
     g_s = &s;
     s.nt = WAVE * nmpcq::QI;

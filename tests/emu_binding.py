@@ -24,7 +24,8 @@ def lib():
         dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
         d, i = C.c_double, C.c_int
         _lib.emu_solve_batch.argtypes = [i, d, d, i, d, d, d, d, d, d, i, d, i,
-                                         dp, dp, dp, dp, dp, dp, ip, ip, ip, dp, i, i, d]
+                                         dp, dp, dp, dp, dp, dp, ip, ip, ip, dp, i, i, d,
+                                         i, d, i, d, i, i, d]
         _lib.emu_solve_batch_quad.argtypes = [i, d, d, i, d, d, d, d, d, d, i,
                                               dp, dp, dp, dp, dp, dp, ip, ip, ip, dp, i, i, i, d]
         _lib.emu_frontend.argtypes = [dp, i, dp, dp, i, dp, dp, dp]
@@ -93,7 +94,9 @@ def solve_batch(cfg, x0, p, W=None, bnd=None, traj=None, cold=True, sqp_max_iter
     rc = lib().emu_solve_batch(N, cfg.dt, cfg.wheelbase, cfg.ipm_max_iter, cfg.ipm_mu0, cfg.ipm_thr0,
                                cfg.ipm_tau, cfg.ipm_tol_mu, cfg.ipm_tol_lin, cfg.ipm_tol_comp,
                                sqp_max_iter, sqp_tol, B, d(x0), d(p), d(W), d(bnd), d(traj), d(ctrl),
-                               i(st), i(it), i(sq), d(cost), 1 if cold else 0, cfg.ipm_stall_iter, cfg.ipm_stall_lin)
+                               i(st), i(it), i(sq), d(cost), 1 if cold else 0, cfg.ipm_stall_iter, cfg.ipm_stall_lin,
+                               cfg.polish, cfg.polish_mu, cfg.polish_tries, cfg.polish_tol, cfg.warm_tries, cfg.warm_gate,
+                               cfg.warm_eps)
     assert rc == 0, "emulated lanes diverged in their sync count"
     return dict(x=traj[:, :, :6].copy(), u=traj[:, :N, 6:].copy(), traj=traj, ctrl=ctrl, status=st,
                 ipm_iters=it, sqp_iters=sq, cost=cost)

@@ -11,6 +11,12 @@ from oracle import oracle as orc
 TOL = 1e-9
 
 
+def _cfg(N, kernel="wave", **over):
+    """The four-slot kernel runs the interior-point iteration to its own termination test (no active-set
+    polish): its oracle counterpart is the same configuration with the polish off."""
+    return orc.default_config(N, 0.35, **(dict(over, polish=0) if kernel == "quad" else over))
+
+
 def _err(g, xo, uo):
     B = xo.shape[0]
     return np.maximum(np.abs(g["x"] - xo).reshape(B, -1).max(1), np.abs(g["u"] - uo).reshape(B, -1).max(1))
@@ -25,7 +31,7 @@ def test_emulated_wave_matches_oracle_cold_and_warm(N, gen, kernel):
     """Both solve kernels: "quad" = four instances per workgroup (SQP-RTI up to N = 63, what nmpc_solve
     launches there), "wave" = one instance per workgroup (SQP mode and longer horizons)."""
     B = 5 if N <= 63 else 3             # (not a multiple of four: three slots of the workgroup run empty at the end)
-    cfg = orc.default_config(N, 0.35)
+    cfg = _cfg(N, kernel)
     x0, p = gen(B)
     g = emu.solve_batch(cfg, x0, p, kernel=kernel)
     xo, uo, so, io = orc.rti_batch(cfg, x0, p)
@@ -50,7 +56,7 @@ def test_emulated_wave_matches_oracle_cold_and_warm(N, gen, kernel):
 @pytest.mark.parametrize("kernel", ["wave", "quad"])
 def test_emulated_wave_per_instance_weights_and_bounds(kernel):
     N, B = 20, 6
-    cfg = orc.default_config(N, 0.35)
+    cfg = _cfg(N, kernel)
     x0, p = sc.config2(B)
     rng = np.random.default_rng(3)
     W = np.array(cfg.W[:])[None, :] * rng.uniform(0.5, 2.0, size=(B, 7))
@@ -58,7 +64,7 @@ def test_emulated_wave_per_instance_weights_and_bounds(kernel):
     bnd[:, 1] *= rng.uniform(0.5, 1.5, size=B); bnd[:, 5] = -bnd[:, 1]
     g = emu.solve_batch(cfg, x0, p, W=W, bnd=bnd, kernel=kernel)
     for i in range(B):
-        oc = orc.default_config(N, 0.35)
+        oc = _cfg(N, kernel)
         for m in range(7):
             oc.W[m] = W[i, m]
         oc.lbu[1], oc.ubu[1] = bnd[i, 1], bnd[i, 5]
@@ -109,7 +115,7 @@ def test_emulated_wave_failure_paths_match_the_oracle(kernel):
     src/AcadosSolver.cpp:56-59) -- same status, same iterate as the oracle; other instances of the
     batch are not affected."""
     N, B = 20, 4
-    cfg = orc.default_config(N, 0.35)
+    cfg = _cfg(N, kernel)
     x0, p = sc.config2(B)
     x0[1, 3] = np.nan
     g = emu.solve_batch(cfg, x0, p, kernel=kernel)
@@ -118,7 +124,7 @@ def test_emulated_wave_failure_paths_match_the_oracle(kernel):
     ok = so == 0
     assert _err(dict(x=g["x"][ok], u=g["u"][ok]), xo[ok], uo[ok]).max() <= 1e-7
     x0, p = sc.config2(B)
-    cfg3 = orc.default_config(N, 0.35, ipm_max_iter=3)
+    cfg3 = _cfg(N, kernel, ipm_max_iter=3)
     g = emu.solve_batch(cfg3, x0, p, kernel=kernel)
     xo, uo, so, io = orc.rti_batch(cfg3, x0, p)
     assert (g["status"] == 4).all() and (so == 4).all() and (g["ipm_iters"] == 3).all()
@@ -137,7 +143,7 @@ def test_emulated_kernels_on_an_ill_conditioned_stage_cost(kernel):
     p1 = (pa[1] + 0.01 * (pa[0] - pa[1]))[None]
     assert 150.0 < p1[0, 2] < 200.0
     for N in (63,):
-        cfg = orc.default_config(N, 0.35)
+        cfg = _cfg(N, kernel)
         xo, uo, so, _ = orc.rti_batch(cfg, xa[1:2], pa[1:2])
         xo2, uo2, so2, io2 = orc.rti_batch(cfg, x1, p1, xo.copy(), uo.copy(), cold=False)
         assert so2[0] == 0

@@ -106,7 +106,12 @@ def check(rc, what):
 def default_config(N=40, dt=0.35, **over):
     cfg = Config()
     check(lib().nmpc_default_config(C.byref(cfg), N, dt), "nmpc_default_config")
-    for k, v in over.items():
+    # NMPC_CFG="polish=0,polish_mu=1e-4": scalar overrides for A/B measurements (tools/, bench.py)
+    env = {}
+    for item in filter(None, os.environ.get("NMPC_CFG", "").split(",")):
+        k, v = item.split("=")
+        env[k.strip()] = type(getattr(cfg, k.strip()))(float(v))
+    for k, v in dict(env, **over).items():
         cur = getattr(cfg, k)
         if hasattr(cur, "__len__"):
             for i, e in enumerate(v):

@@ -537,18 +537,20 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
         // number of corrections the interior-point iteration goes on where it was (its state is not touched).
         // Working sets are packed two bits per pair q (u0,u1,delta,thr): 0 free, 1 at lower, 2 at upper.
         int pol = 0, tries_left = 0, n_pol = 0;    // (uniform) this pass of the loop is an active-set solve; solves so far
-        int wsp = 0, wsprev = -1, ws0 = 0;         // working set, last classification attempted, the iterate's own set
+        int wsp = 0, wsprev = -1;                  // working set, last classification attempted
         int fixm = 0;                              // inputs of this stage fixed by a pin (bit 0: u0, bit 1: u1)
         double gscale = 1.0;                       // size of the gradient entries the multipliers are differences of
         bool polished = false;
-        if (pb.polish) {
+        // a warm QP whose predecessor ended on (nearly) the set its iterate suggested: try the set this iterate
+        // suggests first -- the bounded quantities that sit on a bound (the last polish left them there to round-off)
+        if (pb.polish && hint >= 1.0 && hint <= 1.0 + pb.warm_gate) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (mq[q] && lb[q] - cur[q] >= -pb.warm_eps) ws0 |= 1 << (2 * q);
-                else if (mq[q] && ub[q] - cur[q] <= pb.warm_eps) ws0 |= 2 << (2 * q);
+                if (mq[q] && lb[q] - cur[q] >= -pb.warm_eps) wsp |= 1 << (2 * q);
+                else if (mq[q] && ub[q] - cur[q] <= pb.warm_eps) wsp |= 2 << (2 * q);
             }
-            // a warm QP whose predecessor ended on (nearly) the set its iterate suggested: try that set first
-            if (hint >= 1.0 && hint <= 1.0 + pb.warm_gate) { wsp = ws0; pol = 1; tries_left = pb.warm_tries; }
+            pol = 1;
+            tries_left = pb.warm_tries;
         }
         w.sync();   // BA columns and constant tables visible
         for (;;) {
@@ -855,7 +857,6 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
             // ---- pass 0: forward sweep with the affine right-hand side, then the corrector
             //      pass 1: backward + forward sweep of the corrector increment (homogeneous dynamics)
             double dzs[8];        // affine step of this node (active-set solve: its step)
-            double smq[4] = {0, 0, 0, 0};     // active-set solve: signed multipliers of this node's pins
             double smu = 0.0, csc = 0.0, mu_aff = 0.0;
 #pragma unroll 1
             // (an active-set solve has three passes: forward sweep of its step; backward sweep for the multipliers
@@ -1004,7 +1005,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                         // (this reduction also orders every node's pick-up before the stores below)
                         const double gl = fmax(fmax(fmax(fabs(G0), fabs(G1)), fmax(fabs(G2), fabs(G3))),
                                                fmax(fmax(fabs(G4), fabs(G5)), fmax(fabs(G6), fabs(G7))));
-                        gscale = fmax(1.0, w.max(act ? gl : 0.0));
+                        gscale = w.uniform(fmax(1.0, w.max(act ? gl : 0.0)));
                         if (act) {
                             double *sl = stg + tid * ST + O_D;
                             st2(sl, G0, G1); st2(sl + 2, G6, G7); st2(sl + 4, G2, G3); st2(sl + 6, G4, G5);
@@ -1017,21 +1018,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                         // that of the state bound (next node) the input was fixed by
                         const double *own = stg + (act ? tid : 0) * ST, *prv = ct + (actx ? tid : 1) * ST;
                         const double k0 = own[L::KFF0], k1 = own[L::KFF1];
-                        smq[0] = k0; smq[1] = k1; smq[2] = prv[L::KFF0] * w.rcp(h); smq[3] = prv[L::KFF1] * w.rcp(h);
-                        w.sync();     // every node has read its neighbour's slots
-                        // forward sweep of the refinement: a fixed input stays where it is (no feed-forward), the
-                        // state rows start from zero (homogeneous dynamics)
-                        if (act) {
-                            double *sl = stg + tid * ST;
-                            if (L::kPairOut) st2(sl + L::KFF0, (fixm & 1) ? 0.0 : k0, (fixm & 2) ? 0.0 : k1);
-                            else { sl[L::KFF0] = (fixm & 1) ? 0.0 : k0; sl[L::KFF1] = (fixm & 2) ? 0.0 : k1; }
-                            sl[O_D + 4] = 0.0;
-                        }
-                        w.sync();
-                        w.sweep_priority(true);
-                    } else {
-#pragma unroll
-                        for (int m = 0; m < 8; ++m) dzs[m] += dzl[m];
+                        const double smq[4] = {k0, k1, prv[L::KFF0] * w.rcp(h), prv[L::KFF1] * w.rcp(h)};
                         // KKT conditions of the QP at z + dzs on the working set; its correction where they fail
                         const double tol_d = pb.polish_tol * gscale;
                         int bad = 0, wsn = wsp;
@@ -1046,10 +1033,13 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                             if (mq[q] && s == 2 && !(smq[q] >= -tol_d)) { bad = 1; wsn &= ~(3 << (2 * q)); }
                         }
                         ++n_pol;
+                        // (the reduction also orders every node's reads of its neighbour's slots before the stores below)
                         if (w.max(bad ? 1.0 : 0.0) == 0.0) {
-                            // the vertex: pinned quantities sit on their bounds to round-off, complementarity is exact
-#pragma unroll
-                            for (int m = 0; m < 8; ++m) z[m] += dzs[m];
+                            // the vertex: pinned quantities sit on their bounds to round-off, complementarity is
+                            // exact.  One step of iterative refinement follows (pass 2): the backward sweep just
+                            // run is its first half -- the gradient at the new point is the residual of the
+                            // solve -- and a forward sweep in which a fixed input stays where it is (no
+                            // feed-forward) and the state rows start from zero (homogeneous dynamics) the second.
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 const int s = NMPC_WSQ(wsp, q);
@@ -1057,12 +1047,22 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                                 lu[q] = (mq[q] && s == 2) ? fmax(smq[q], 0.0) : 0.0;
                             }
                             polished = true;
-                        } else if (tries_left > 0) {
-                            --tries_left;
-                            wsp = wsn;
+                            if (act) {
+                                double *sl = stg + tid * ST;
+                                if (L::kPairOut) st2(sl + L::KFF0, (fixm & 1) ? 0.0 : k0, (fixm & 2) ? 0.0 : k1);
+                                else { sl[L::KFF0] = (fixm & 1) ? 0.0 : k0; sl[L::KFF1] = (fixm & 2) ? 0.0 : k1; }
+                                sl[O_D + 4] = 0.0;
+                            }
+                            w.sync();
+                            w.sweep_priority(true);
                         } else {
-                            pol = 0;        // the interior-point iteration goes on from where it was
+                            if (tries_left > 0) { --tries_left; wsp = wsn; }
+                            else pol = 0;        // the interior-point iteration goes on from where it was
+                            break;               // (no refinement of a rejected solve)
                         }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < 8; ++m) z[m] += dzs[m] + dzl[m];
                     }
                 } else if (pass == 0) {
                     // E-B: affine step lengths, centring parameter, corrector right-hand side
@@ -1149,7 +1149,6 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     lin_scale *= (1.0 - alpha);
                     ++it;
                 }
-                if (polished) break;
             }
             if (polished) { qp_status = 0; break; }
         }
@@ -1157,7 +1156,11 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
         if (polished) {
             int mm = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) mm += NMPC_WSQ(wsp, q) != NMPC_WSQ(ws0, q);
+            for (int q = 0; q < 4; ++q) {
+                // (the iterate's own set again: cheaper than a register held through the whole iteration)
+                const int s0 = !mq[q] ? 0 : lb[q] - cur[q] >= -pb.warm_eps ? 1 : ub[q] - cur[q] <= pb.warm_eps ? 2 : 0;
+                mm += NMPC_WSQ(wsp, q) != s0;
+            }
             hint = w.uniform(1.0 + w.sum((double)mm));
         } else {
             hint = 0.0;

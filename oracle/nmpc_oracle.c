@@ -524,18 +524,17 @@ static int polish_attempt(const orc_config *cfg, const orc_qp *qp, const double 
        first result (gradient, shooting gaps and bound distances re-evaluated there) */
     double *rm = orc_ws_get(3, (size_t)N * (8 + 6) + nb * 3 + (size_t)(N + 1) * NZ);
     if (!rm) return -1;
-    double *g2 = rm, *b2 = g2 + (size_t)N * 8, *lo2 = b2 + (size_t)N * 6, *up2 = lo2 + nb, *dlt = up2 + nb;
+    double *g2 = rm, *b2 = g2 + (size_t)N * 8, *lo2 = b2 + (size_t)N * 6, *up2 = lo2 + nb, *rsm = up2 + nb, *dlt = rsm + nb;
     for (int tr = 0;; ++tr) {
         /* an input pinned together with the state it integrates into (node k+1) leaves stage k with dependent
            rows: keep the state's pin, free the input (if its bound then fails, the correction below says so) */
         for (int k = 0; k + 1 < N; ++k)
             for (int a = 0; a < NU; ++a)
                 if (ws[k * NB + a] != 0 && ws[(k + 1) * NB + 2 + a] != 0) ws[k * NB + a] = 0;
-        /* two solves in increments: from the caller's point z0 (the interior-point iterate: a short step, so
-           round-off stays relative to the step), then once more from the result (iterative refinement; its
-           adjoint recursion gives the multipliers) */
-        double gscale = 1.0;     /* size of the gradient entries the multipliers are differences of */
+        /* the solve in increments from the caller's point z0 (the interior-point iterate: a short step, so
+           round-off stays relative to the step) */
         memcpy(z, z0, sizeof(double) * (size_t)(N + 1) * NZ);
+        double gscale = 1.0;     /* size of the gradient entries the multipliers are differences of */
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1) gscale = 1.0;
             for (int k = 0; k < N; ++k) {
@@ -558,6 +557,7 @@ static int polish_attempt(const orc_config *cfg, const orc_qp *qp, const double 
                     up2[k * NB + j] = up[k * NB + j] - v;
                 }
             }
+            if (pass == 1) break;       /* (the second pass only evaluates the gradient at the result) */
             orc_qp q2 = *qp;
             q2.g = g2; q2.b = b2;
             memset(dlt, 0, sizeof(double) * (size_t)(N + 1) * NZ);     /* dx_0 increment: none */
@@ -573,6 +573,15 @@ static int polish_attempt(const orc_config *cfg, const orc_qp *qp, const double 
             if (ws[q] == 0) { if (!(v >= lo[q] - tol) || !(v <= up[q] + tol)) bad = 1; }
             else if (ws[q] < 0) { if (!(sm[q] <= told)) bad = 1; }
             else { if (!(sm[q] >= -told)) bad = 1; }
+        }
+        if (!bad) {
+            /* accepted; one step of iterative refinement: the same solve once more, in increments from the
+               result (g2, b2, lo2, up2 hold gradient, gaps and bound distances there) */
+            orc_qp q2 = *qp;
+            q2.g = g2; q2.b = b2;
+            memset(dlt, 0, sizeof(double) * (size_t)(N + 1) * NZ);
+            if (orc_ws_solve(&q2, lo2, up2, ws, dlt, rsm) == 0)
+                for (int i = 0; i < (N + 1) * NZ; ++i) z[i] += dlt[i];
         }
         if (!bad) return 1;
         if (tr >= tries) return 0;

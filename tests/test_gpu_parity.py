@@ -17,8 +17,10 @@ TOL = 1e-9        # design target
 TOL_BAR = 1e-6    # north_star bar, met by every instance
 
 
-def _ocfg(N, dt=0.35):
-    return orc.config_like(capi.default_config(N, dt))
+def _ocfg(N, dt=0.35, **over):
+    """The oracle's configuration = the library's (every same-named field), e.g. _ocfg(N, polish=0) for the
+    four-slot kernel, which runs the interior-point iteration to its own termination test."""
+    return orc.config_like(capi.default_config(N, dt, **over))
 
 
 def _scale(x, u):
@@ -59,14 +61,16 @@ def test_cold_then_warm_rti_matches_oracle(N):
     s.set_params(p)
     ocfg = _ocfg(N)
     xo = uo = None
+    hint = np.zeros(B)    # the oracle's copy of the warm-start hints the library keeps with its iterates
     for it in range(3):   # 1 cold + 2 warm RTI iterations, no shift
         if it and N > 40:
             # long horizons: an unconverged RTI sequence amplifies round-off by ~1e4 per call
             # (the CPU lane emulator shows the same), so restart both sides from one iterate
             s.set_iterate(xo, uo)
+            hint[:] = 0.0          # (a new iterate carries no hint)
         s.solve(B)
         g = s.get(B)
-        xo, uo, so, io = orc.rti_batch(ocfg, x0, p, xo, uo, cold=(it == 0))
+        xo, uo, so, io = orc.rti_batch(ocfg, x0, p, xo, uo, cold=(it == 0), hint=hint)
         assert (g["status"] == 0).all() and (so == 0).all()
         assert_parity(g, xo, uo, io)
         # same interior-point path modulo round-off at the termination threshold
@@ -83,6 +87,7 @@ def test_new_measurement_each_tick_warm_start():
     s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
     ocfg = _ocfg(N)
     xo = uo = None
+    hint = np.zeros(B)
     for tick in range(3):
         x0, p = sc.config2(B, start=1000 * tick)
         if tick:   # keep it a plausible perturbation of the previous tick
@@ -93,7 +98,7 @@ def test_new_measurement_each_tick_warm_start():
         s.set_params(p)
         s.solve(B)
         g = s.get(B)
-        xo, uo, so, io = orc.rti_batch(ocfg, x0, p, xo, uo, cold=(tick == 0))
+        xo, uo, so, io = orc.rti_batch(ocfg, x0, p, xo, uo, cold=(tick == 0), hint=hint)
         ok = (so == 0) & (g["status"] == 0)
         assert ok.mean() > 0.95
         assert_parity(g, xo, uo, io, ok=ok)

@@ -213,7 +213,7 @@ def test_quad_kernel_matches_oracle(N, monkeypatch):
     cold + two warm calls, batch sizes that leave slots empty, more instances than slots, and the failure
     statuses.  The default kernel is checked by test_gpu_parity.py."""
     monkeypatch.setenv("NMPC_KERNEL", "quad")
-    ocfg = _ocfg(N)
+    ocfg = _ocfg(N, polish=0)       # (this kernel runs the interior-point iteration to the end: no active-set polish)
     for B in (1, 7, 1500):
         x0, p = sc.config2(B)
         s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
@@ -250,7 +250,7 @@ def test_quad_kernel_matches_oracle(N, monkeypatch):
     s.solve(B)              # the failed one restarts cold, the others are warm
     assert (s.get(B)["status"] == 0).all()
     s.close()
-    c = capi.default_config(N, 0.35)
+    c = capi.default_config(N, 0.35, polish=0)
     c.ipm_max_iter = 3
     s = capi.BatchSolver(cfg=c, capacity=B)
     s.set_x0(x0)
@@ -273,7 +273,7 @@ def test_quad_kernel_full_batch_and_weights(monkeypatch):
     out = {}
     for kern in ("quad", "wave"):
         monkeypatch.setenv("NMPC_KERNEL", kern)
-        s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
+        s = capi.BatchSolver(N=N, dt=0.35, capacity=B, polish=0)     # (the same algorithm on both: interior point to the end)
         s.set_x0(x0)
         s.set_params(p)
         s.set_weights(W)
@@ -290,15 +290,17 @@ def test_quad_kernel_full_batch_and_weights(monkeypatch):
 
 
 def test_kernel_choice_by_batch_and_horizon(monkeypatch):
-    """Without NMPC_KERNEL the library picks the four-slot kernel for 32 <= N <= 43 and B >= 8192 and the
-    one-instance kernel otherwise (nmpc_hip.hip: use_quad_kernel).  Seen from outside: the automatic
-    choice is bit-identical to the forced kernel it should have picked, and both kernels agree to the bar."""
-    def run(N, B, kern):
+    """Without NMPC_KERNEL and with the active-set polish off the library picks the four-slot kernel for
+    32 <= N <= 43 and B >= 8192 and the one-instance kernel otherwise; with the polish on (the default) always
+    the one-instance kernel, the only one that has it (nmpc_hip.hip: use_quad_kernel).  Seen from outside: the
+    automatic choice is bit-identical to the forced kernel it should have picked, and both kernels agree to
+    the bar."""
+    def run(N, B, kern, polish=0):
         if kern is None:
             monkeypatch.delenv("NMPC_KERNEL", raising=False)
         else:
             monkeypatch.setenv("NMPC_KERNEL", kern)
-        s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
+        s = capi.BatchSolver(N=N, dt=0.35, capacity=B, polish=polish)
         x0, p = sc.config2(B)
         s.set_x0(x0)
         s.set_params(p)
@@ -313,6 +315,11 @@ def test_kernel_choice_by_batch_and_horizon(monkeypatch):
         assert not np.array_equal(quad["x"], wave["x"])          # (the two kernels round differently)
         assert (_err(quad, wave["x"], wave["u"]) <= TOL_BAR * _scale(wave["x"], wave["u"])).all()
         assert (auto["status"] == 0).mean() > 0.999
+    # the default configuration (polish on): the one-instance kernel whatever the batch, and the same minimisers
+    auto, wave, quad = run(40, 8192, None, polish=1), run(40, 8192, "wave", polish=1), run(40, 8192, "quad")
+    assert np.array_equal(auto["x"], wave["x"]) and np.array_equal(auto["u"], wave["u"])
+    assert (_err(quad, wave["x"], wave["u"]) <= TOL_BAR * _scale(wave["x"], wave["u"])).all()
+    assert auto["ipm_iters"].mean() < quad["ipm_iters"].mean() - 1.5
 
 
 def test_horizon_sweep_inside_one_launch():
@@ -471,8 +478,9 @@ def test_stalled_interior_point_iterations_fail_early():
         s.solve(B)                                  # warm call on moved inputs
         g = s.get(B)
         oc = orc.config_like(c)
-        xo, uo, _, _ = orc.rti_batch(oc, host[0][0], host[0][1])
-        xo, uo, so, io = orc.rti_batch(oc, x1, p1, xo, uo, cold=False)
+        hint = np.zeros(B)
+        xo, uo, _, _ = orc.rti_batch(oc, host[0][0], host[0][1], hint=hint)
+        xo, uo, so, io = orc.rti_batch(oc, x1, p1, xo, uo, cold=False, hint=hint)
         assert np.array_equal(g["status"], so)
         assert (np.abs(g["ipm_iters"] - io) <= 1).all()
         ok = so == 0
@@ -482,9 +490,10 @@ def test_stalled_interior_point_iterations_fail_early():
     st_on, it_on = out[20]
     st_off, it_off = out[0]
     failed = st_off == 4
-    assert failed.sum() >= 1 and (it_off[failed] == 50).all()
+    # (reported counts include the active-set solves of attempts that were not accepted: a handful at most)
+    assert failed.sum() >= 1 and (it_off[failed] >= 50).all() and (it_off[failed] <= 56).all()
     assert np.array_equal(st_on == 4, failed)                  # the same instances fail, ...
-    assert (it_on[failed] == 20).all()                         # ... thirty iterations earlier
+    assert (it_on[failed] >= 20).all() and (it_on[failed] <= 26).all()   # ... thirty iterations earlier
     assert np.array_equal(it_on[~failed], it_off[~failed])     # nothing else changes
 
 
@@ -561,7 +570,7 @@ def test_ill_conditioned_stage_costs_both_kernels(kern, monkeypatch):
     x1 = xa[1:] + 0.01 * (xa[:-1] - xa[1:])
     p1 = pa[1:] + 0.01 * (pa[:-1] - pa[1:])
     for N in (40, 63):
-        ocfg = _ocfg(N)
+        ocfg = _ocfg(N, polish=0 if kern == "quad" else 1)
         xo, uo, so, _ = orc.rti_batch(ocfg, xa[1:], pa[1:])
         xo2, uo2, so2, io2 = orc.rti_batch(ocfg, x1, p1, xo.copy(), uo.copy(), cold=False)
         s = capi.BatchSolver(N=N, dt=0.35, capacity=B)

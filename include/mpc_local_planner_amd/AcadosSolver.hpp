@@ -62,19 +62,26 @@ class Solver {
     Solver(const Solver &) = delete;             // the reference's class double-frees when copied
     Solver &operator=(const Solver &) = delete;
 
-    // AcadosSolver.cpp:8-13 frees the capsule, creates a new one and sets the cold guess.  The capsule
-    // there holds ONE solver and nothing else; the handle here also holds the track, per-instance
-    // weights / bounds, redirected control records and the warm iterates of the other capacity-1
-    // instances, so the same effect -- solver state of this instance back to the cold guess -- is
-    // reached without tearing the handle down (the kernel flags failed instances for a cold start
-    // by itself; this makes it explicit for instance 0, the one solve() drives).  The cold flag is set
-    // after the guess, so the next solve starts from ITS measurement (x_k = x0, u_k = 0): the same as
-    // setInitGuess(state) when the measurement has not moved, and not poisoned by a NaN state otherwise.
+    // AcadosSolver.cpp:8-13 frees the capsule, creates a new one and sets the cold guess from the state of
+    // the failing call: the next solve starts from x_k = that state, u_k = 0, whatever it measures then.
+    // The capsule there holds ONE solver and nothing else; the handle here also holds the track,
+    // per-instance weights / bounds, redirected control records and the warm iterates of the other
+    // capacity-1 instances, so the same effect -- solver state of instance 0 (the one solve() drives) back
+    // to that guess -- is reached without tearing the handle down: nmpc_set_iterate installs the guess and
+    // clears the cold-start flag the kernel raised for the failed instance.  A state that is not finite
+    // (the failure was a NaN measurement) cannot serve as a guess: then the instance is flagged cold
+    // instead and starts from its NEXT measurement.
     void reInit(const State &state) {
         if (!handle_) init();
-        setInitGuess(state);
-        const uint8_t first = 1;
-        check(nmpc_reset(handle_, &first, 1), "nmpc_reset");
+        const auto s = state.toArray();
+        bool finite = true;
+        for (double v : s) finite = finite && (v - v == 0.0);
+        if (finite) {
+            setInitGuess(state);
+        } else {
+            const uint8_t first = 1;
+            check(nmpc_reset(handle_, &first, 1), "nmpc_reset");
+        }
     }
 
     void setInitCondition(const State &state) {  // AcadosSolver.cpp:15-26: lbx0 = ubx0 = x0
@@ -201,16 +208,18 @@ class PathTracking : public Solver {
         check(nmpc_set_x0(handle_, x0.data(), B), "nmpc_set_x0");
         check(nmpc_set_params(handle_, p.data(), B), "nmpc_set_params");
         check(nmpc_solve(handle_, B, run_.mode, sqpMaxIter_, sqpTol_), "nmpc_solve");
-        std::vector<double> x(static_cast<size_t>(B) * (N + 1) * 6), u(static_cast<size_t>(B) * N * 2);
+        // the horizons are read once, to pack the MPCReturns: straight from the handle's pinned host buffers
+        const double *x = nullptr, *u = nullptr;
         std::vector<int32_t> status(static_cast<size_t>(B));
-        check(nmpc_get(handle_, B, x.data(), u.data(), status.data(), nullptr, nullptr, nullptr), "nmpc_get");
+        check(nmpc_get(handle_, B, nullptr, nullptr, status.data(), nullptr, nullptr, nullptr), "nmpc_get");
+        check(nmpc_get_view(handle_, B, &x, &u), "nmpc_get_view");
         const auto end = std::chrono::high_resolution_clock::now();
         const double ms = static_cast<double>(
             std::chrono::duration_cast<std::chrono::milliseconds>(end - start).count());
         std::vector<MPCReturn> out(static_cast<size_t>(B));
         for (int b = 0; b < B; ++b) {
-            out[static_cast<size_t>(b)] = pack(x.data() + static_cast<size_t>(b) * (N + 1) * 6,
-                                               u.data() + static_cast<size_t>(b) * N * 2, N,
+            out[static_cast<size_t>(b)] = pack(x + static_cast<size_t>(b) * (N + 1) * 6,
+                                               u + static_cast<size_t>(b) * N * 2, N,
                                                status[static_cast<size_t>(b)]);
             out[static_cast<size_t>(b)].computeTime = ms;
         }

@@ -163,9 +163,17 @@ int nmpc_solve(nmpc_handle *h, int B, int mode, int max_iter, double tol);
 int nmpc_sync(nmpc_handle *h);
 
 /* Replaces ocp_nlp_out_get "x"/"u" (src/AcadosSolver.cpp:51-54).  Any output may be NULL.
- * Synchronises the handle's stream. */
+ * Synchronises the handle's stream.  (x / u are split on the device and staged through pinned host memory
+ * that the handle allocates at the first call asking for them; later calls allocate nothing.) */
 int nmpc_get(nmpc_handle *h, int B, double *x, double *u, int32_t *status, double *cost,
              int32_t *ipm_iters, int32_t *sqp_iters);
+
+/* The same trajectories without the copy into caller memory: *x and *u point at x[B][N+1][6] / u[B][N][2] in
+ * pinned host memory owned by the handle, valid until the next nmpc_get / nmpc_get_view / nmpc_destroy of this
+ * handle.  Replaces the same ocp_nlp_out_get loop (src/AcadosSolver.cpp:51-54) for callers that read the
+ * horizon once (the MPCReturn packing of src/AcadosSolver.cpp:64-70 does).  x and u are split on the device
+ * and arrive by one DMA each.  Synchronises the handle's stream. */
+int nmpc_get_view(nmpc_handle *h, int B, const double **x, const double **u);
 
 /* Per-instance control record [B][6]: u0.deltaDot, u0.throttleDot, x[1].delta, x[1].throttle
  * (what src/RosMpc.cpp:82-86 sends to the car), cost, status + 16*ipm_iters. */
@@ -200,6 +208,17 @@ int nmpc_get_world_path(nmpc_handle *h, int B, double *xy);
 int nmpc_closed_loop(nmpc_handle *h, int B, int steps, double dt_plant, double steering_ratio,
                      double *world_state, const double *pitch_vref, double *trace, int32_t *n_failed);
 
+/* The same loop with the other branch of the reference's actuation rule, use_actual_steering_topic = true
+ * (src/RosMpc.cpp:25,88-90,150): the steering angle of the state is not the commanded one fed back but a
+ * measurement -- steer_meas[steps][B] are the steering-WHEEL angles of the actual-steering topic as they
+ * arrive before each tick's solve (state delta = angle / steering_ratio, actualSteeringCallback); the car
+ * moves with that angle during the tick.  Throttle is fed back as before (prevThrottle, src/RosMpc.cpp:84).
+ * commands (optional) receives what src/RosMpc.cpp:82-86 publishes per tick, [steps][B][2] =
+ * x[1].delta * steering_ratio, x[1].throttle -- the input of the caller's steering actuator. */
+int nmpc_closed_loop_measured(nmpc_handle *h, int B, int steps, double dt_plant, double steering_ratio,
+                              double *world_state, const double *pitch_vref, const double *steer_meas,
+                              double *commands, double *trace, int32_t *n_failed);
+
 /* One SQP-RTI iteration of instances 0..B-1 (what nmpc_solve does in NMPC_MODE_RTI) WITHOUT a handle and
  * without any allocation.  No counterpart in the reference: it exists for callers that cannot allocate
  * device memory -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
@@ -212,8 +231,11 @@ int nmpc_closed_loop(nmpc_handle *h, int B, int steps, double dt_plant, double s
  *   inputs  (device): d_x0[B][6], d_p[B][6], d_W[B][7] or NULL, d_bnd[B][8] or NULL (NULL = cfg's values)
  *   in/out  (device): d_traj[B][N+1][8] iterate per node X,Y,psi,v,delta,thr,u0,u1 (nmpc_device_ptr(h, 1)
  *                     layout); d_ipm_iters int32[B] (read when cold == 0: previous counts order the launch)
- *   outputs (device): d_ctrl[B][6] control records (nmpc_get_controls layout), d_status int32[B]
- * Results are bit-identical to nmpc_solve on the same inputs.  All calls on one GPU share that GPU's
+ *                     d_status int32[B] (read when cold == 0: an instance whose previous status is not 0
+ *                     starts cold, as the handle's own flags make it in nmpc_solve and as the reference
+ *                     re-initialises after every failure, src/AcadosSolver.cpp:56-59; written with the new status)
+ *   outputs (device): d_ctrl[B][6] control records (nmpc_get_controls layout)
+ * Results are bit-identical to nmpc_solve on the same inputs (a warm call: given the statuses nmpc_solve left).  All calls on one GPU share that GPU's
  * workspace: calls that overlap on one GPU (different streams or threads) race -- serialise them. */
 #define NMPC_STATIC_MAX_BATCH 16384
 int nmpc_solve_static(const nmpc_config *cfg, int device, void *stream, int B, int cold, const double *d_x0,

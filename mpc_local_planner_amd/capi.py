@@ -39,9 +39,9 @@ EXPORTS = [
     "nmpc_default_config", "nmpc_config_from_file", "nmpc_create", "nmpc_destroy", "nmpc_set_x0", "nmpc_set_params",
     "nmpc_set_inputs_device", "nmpc_set_weights", "nmpc_set_bounds", "nmpc_set_horizons", "nmpc_reset", "nmpc_set_iterate",
     "nmpc_solve", "nmpc_solve_static",
-    "nmpc_sync", "nmpc_get", "nmpc_get_controls", "nmpc_device_ptr", "nmpc_stream", "nmpc_set_controls_device",
+    "nmpc_sync", "nmpc_get", "nmpc_get_view", "nmpc_get_controls", "nmpc_device_ptr", "nmpc_stream", "nmpc_set_controls_device",
     "nmpc_capacity", "nmpc_horizon", "nmpc_last_error", "nmpc_gather_controls", "nmpc_shard_range",
-    "nmpc_set_track", "nmpc_frontend", "nmpc_get_frontend", "nmpc_get_world_path", "nmpc_closed_loop",
+    "nmpc_set_track", "nmpc_frontend", "nmpc_get_frontend", "nmpc_get_world_path", "nmpc_closed_loop", "nmpc_closed_loop_measured",
 ]
 
 _lib = None
@@ -78,6 +78,7 @@ def lib():
     l.nmpc_solve_static.argtypes = [C.POINTER(Config), C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     l.nmpc_sync.argtypes = [vp]
     l.nmpc_get.argtypes = [vp, C.c_int, dp, dp, ip, dp, ip, ip]
+    l.nmpc_get_view.argtypes = [vp, C.c_int, C.POINTER(dp), C.POINTER(dp)]
     l.nmpc_get_controls.argtypes = [vp, C.c_int, dp]
     l.nmpc_device_ptr.argtypes = [vp, C.c_int]
     l.nmpc_device_ptr.restype = vp
@@ -94,6 +95,7 @@ def lib():
     l.nmpc_get_frontend.argtypes = [vp, C.c_int, dp, dp, dp]
     l.nmpc_get_world_path.argtypes = [vp, C.c_int, dp]
     l.nmpc_closed_loop.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double, dp, dp, dp, ip]
+    l.nmpc_closed_loop_measured.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double, dp, dp, dp, dp, dp, ip]
     _lib = l
     return l
 
@@ -225,6 +227,16 @@ class BatchSolver:
         check(lib().nmpc_get(self._h, B, _dp(x), _dp(u), _ip(status), _dp(cost), _ip(it), _ip(sq)), "nmpc_get")
         return dict(x=x, u=u, status=status, cost=cost, ipm_iters=it, sqp_iters=sq)
 
+    def get_view(self, B=None):
+        """(x[B, N+1, 6], u[B, N, 2]) as numpy views of the handle's pinned host buffers: no copy; valid until
+        the next get / get_view / close of this solver."""
+        B = B or self.capacity
+        px, pu = C.POINTER(C.c_double)(), C.POINTER(C.c_double)()
+        check(lib().nmpc_get_view(self._h, B, C.byref(px), C.byref(pu)), "nmpc_get_view")
+        x = np.ctypeslib.as_array(px, shape=(B, self.N + 1, 6))
+        u = np.ctypeslib.as_array(pu, shape=(B, self.N, 2))
+        return x, u
+
     def get_controls(self, B=None):
         B = B or self.capacity
         c = np.zeros((B, 6))
@@ -255,12 +267,22 @@ class BatchSolver:
         return xy
 
     def closed_loop(self, world_state, pitch_vref, steps, dt_plant=1.0 / 30.0, steering_ratio=1.0,
-                    trace=False, count_failures=False):
+                    trace=False, count_failures=False, steer_meas=None):
+        """steer_meas[steps, B] (steering-wheel angles of the actual-steering topic, one row per tick) selects
+        the use_actual_steering_topic = true branch; the return then has the published commands
+        [steps, B, 2] as a fourth element."""
         ws = np.array(world_state, dtype=np.float64).reshape(-1, 6)
         pv = np.ascontiguousarray(pitch_vref, dtype=np.float64).reshape(-1, 2)
         B = ws.shape[0]
         tr = np.zeros((steps, B, 6)) if trace else None
         nf = C.c_int32(0)
+        if steer_meas is not None:
+            sm = np.ascontiguousarray(steer_meas, dtype=np.float64).reshape(steps, B)
+            cmd = np.zeros((steps, B, 2))
+            check(lib().nmpc_closed_loop_measured(self._h, B, steps, dt_plant, steering_ratio, _dp(ws), _dp(pv), _dp(sm),
+                                                  _dp(cmd), _dp(tr) if trace else None,
+                                                  C.byref(nf) if count_failures else None), "nmpc_closed_loop_measured")
+            return ws, tr, nf.value, cmd
         check(lib().nmpc_closed_loop(self._h, B, steps, dt_plant, steering_ratio, _dp(ws), _dp(pv),
                                      _dp(tr) if trace else None, C.byref(nf) if count_failures else None),
               "nmpc_closed_loop")

@@ -202,10 +202,13 @@ NMPC_DEV void unrotate(const double *ws, double rotation, double lx, double ly, 
 // Closed-loop plant: classical RK4 of (X,Y,psi,v) over `dtp` seconds with
 // the commanded steering angle and throttle held, then the reference's feedback rule
 // (src/RosMpc.cpp:81-90): delta <- (x1.delta * ratio) / ratio, throttle <- x1.throttle.
+// measured != 0 is the other branch of that rule (use_actual_steering_topic = true, src/RosMpc.cpp:88-90,150):
+// the steering angle of the state comes from a measurement, not from the command -- the car moves with the
+// angle it has (ws[4], set from the measurement before the solve) and that entry is left alone.
 NMPC_DEV void plant_step(double *ws, double delta_cmd, double thr_cmd, double pitch, double dtp,
-                         double inv_wheelbase, double steering_ratio)
+                         double inv_wheelbase, double steering_ratio, int measured = 0)
 {
-    const double delta = (delta_cmd * steering_ratio) / steering_ratio;
+    const double delta = measured ? ws[4] : (delta_cmd * steering_ratio) / steering_ratio;
     const double td = tan(delta) * inv_wheelbase, gp = sin(pitch) * 9.81;
     double s[4] = {ws[0], ws[1], ws[2], ws[3]}, acc[4] = {0, 0, 0, 0}, k[4] = {0, 0, 0, 0};
 #pragma unroll

@@ -366,13 +366,13 @@ __global__ void __launch_bounds__(64 * NW, 2) nmpc_solve_kernel(KernelArgs a)
 }
 
 // ---- four instances per workgroup (nmpc_quad_solver.h): waves 0..3 are slots that do the
-// element-wise work of one instance each, the fifth wave sweeps all four (one per 16-lane DPP row).
+// element-wise work of one instance each; wave 0 also sweeps all four (one per 16-lane DPP row).
 // Shares the vector-sweep stages, reductions and reciprocal with the one-wave policy.
 constexpr int QUAD_THREADS = 64 * nmpcq::QI;
 struct GpuQuad : GpuWave<1, false> {
     __device__ __forceinline__ int wave() const { return (int)threadIdx.x >> 6; }
     __device__ __forceinline__ bool sweeper() const { return ((int)threadIdx.x >> 6) == 0; }   // slot 0's wave also sweeps
-    // all five waves (the hardware barrier counts arriving waves, whichever branch they are in)
+    // all four waves (the hardware barrier counts arriving waves, whichever branch they are in)
     __device__ __forceinline__ void sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
     __device__ __forceinline__ bool uniform_flag(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
     // next ticket of the launch-wide queue: one atomic add per wave, the same value on every lane
@@ -432,17 +432,25 @@ __global__ void nmpc_unrotate_kernel(const double *traj, const double *ws, const
 }
 
 __global__ void nmpc_plant_kernel(double *ws, const double *pv, const double *ctrl, int B, double dtp,
-                                  double inv_wheelbase, double steering_ratio)
+                                  double inv_wheelbase, double steering_ratio, int measured, double *cmd)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
     double w[6];
 #pragma unroll
     for (int m = 0; m < 6; ++m) w[m] = ws[(size_t)i * 6 + m];
-    nmpcf::plant_step(w, ctrl[(size_t)i * 6 + 2], ctrl[(size_t)i * 6 + 3], pv[(size_t)i * 2], dtp, inv_wheelbase,
-                      steering_ratio);
+    const double dcmd = ctrl[(size_t)i * 6 + 2], tcmd = ctrl[(size_t)i * 6 + 3];
+    nmpcf::plant_step(w, dcmd, tcmd, pv[(size_t)i * 2], dtp, inv_wheelbase, steering_ratio, measured);
 #pragma unroll
     for (int m = 0; m < 6; ++m) ws[(size_t)i * 6 + m] = w[m];
+    if (cmd) { cmd[(size_t)i * 2] = dcmd * steering_ratio; cmd[(size_t)i * 2 + 1] = tcmd; }   // what src/RosMpc.cpp:82-86 publishes
+}
+
+// actualSteeringCallback (src/RosMpc.cpp:150): currentSteeringAngle_ = msg / steeringRatio_
+__global__ void nmpc_measured_steering_kernel(double *ws, const double *wheel_angle, int B, double steering_ratio)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) ws[(size_t)i * 6 + 4] = wheel_angle[i] / steering_ratio;
 }
 
 // Launch order for the next solve: instances sorted by the interior-point iterations of their
@@ -481,6 +489,19 @@ __global__ void __launch_bounds__(1024) nmpc_order_kernel(const int *iters, int 
     }
 }
 
+// iterate [B][N+1][8] (per node X,Y,psi,v,delta,thr,u0,u1) -> the C ABI's x[B][N+1][6] and u[B][N][2]
+__global__ void nmpc_split_kernel(const double *traj, int B, int N, double *xs, double *us)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t N1 = (size_t)N + 1;
+    if (t >= (size_t)B * N1) return;
+    const size_t b = t / N1, k = t % N1;
+    const double *r = traj + t * 8;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) xs[t * 6 + m] = r[m];
+    if (k < (size_t)N) { us[(b * N + k) * 2] = r[6]; us[(b * N + k) * 2 + 1] = r[7]; }
+}
+
 __global__ void nmpc_fill_rows_kernel(double *dst, int rows, int width, const double *vals8)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -489,6 +510,17 @@ __global__ void nmpc_fill_rows_kernel(double *dst, int rows, int width, const do
 
 // cold-start flags; a reset instance also forgets its iteration history (what the launch order is
 // built from): the work of a cold solve is unrelated to that of the last warm one
+// warm call of nmpc_solve_static: an instance whose previous solve did not return status 0 starts cold, as
+// nmpc_solve does it (the reference re-initialises on every status != ACADOS_SUCCESS, src/AcadosSolver.cpp:56-59)
+__global__ void nmpc_reset_from_status_kernel(unsigned char *dst, const int *status, int B, int *iters)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const bool failed = status[i] != 0;
+    dst[i] = failed ? 1 : 0;
+    if (failed) iters[i] = 0;
+}
+
 __global__ void nmpc_set_reset_kernel(unsigned char *dst, const unsigned char *mask, int B, int *iters)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -529,7 +561,10 @@ struct nmpc_handle {
     KernelChoice kernel;          // NMPC_KERNEL at creation (auto / wave / quad, see use_quad_kernel)
     const double *in_x0, *in_p;   // what the kernel reads (own buffers or caller's device buffers)
     double *out_ctrl;             // where the control records go (own buffer or the caller's device buffer)
-    std::vector<double> h_traj;
+    std::vector<double> h_traj;   // nmpc_set_iterate's host image
+    // trajectories out (nmpc_get / nmpc_get_view): x and u split on the device, then one DMA each into pinned
+    // host memory owned by the handle; allocated at the first call that asks for trajectories
+    double *d_xs = nullptr, *d_us = nullptr, *h_px = nullptr, *h_pu = nullptr;
     // path front-end / closed loop (allocated by nmpc_set_track)
     double *d_track = nullptr, *d_ws = nullptr, *d_pv = nullptr, *d_rot = nullptr, *d_xy = nullptr;
     double *d_wsfe = nullptr;     // the world states the last front-end pass transformed (the plant moves d_ws on)
@@ -564,7 +599,7 @@ static void fill_problem(const nmpc_config &c, int mode, int max_iter, double to
 
 // Which solve kernel.  Two implement SQP-RTI up to N = 63: one instance per workgroup
 // (nmpc_wave_solver.h) and four slots per workgroup fed from a ticket queue (nmpc_quad_solver.h).
-// Measured (gpurun_out -> profiles/r2/quad_vs_wave.md): the four-slot kernel is 1-8 % faster where two
+// Measured (profiles/r2/quad_vs_wave_by_horizon_after_symmetrisation.txt): the four-slot kernel is 1-8 % faster where two
 // of its workgroups fit into a CU's LDS (N <= 43) and the sweeps are long enough to pay for its four
 // workgroup barriers per iteration (N >= 32), once the batch fills the chip several times over; it is
 // slower for short horizons, by 25 % where only one workgroup fits, and has the longer single-solve
@@ -578,7 +613,30 @@ static KernelChoice kernel_choice()
     if (e && strcmp(e, "wave") == 0) return KERNEL_WAVE;
     return KERNEL_AUTO;
 }
-static bool use_quad_kernel(KernelChoice c, int mode, int N, int B, bool polish)
+// Compute units and LDS per compute unit of a device, asked once per device (MI355X: 256 and 160 KiB; other
+// parts or partition modes differ, and the grid of the four-slot kernel and its LDS test follow them).
+struct DeviceShape { int cus, lds_per_cu; };
+static DeviceShape device_shape(int device)
+{
+    static std::mutex mu;
+    static DeviceShape cache[64];
+    static bool have[64];
+    std::lock_guard<std::mutex> lk(mu);
+    const int d = (device >= 0 && device < 64) ? device : 0;
+    if (!have[d]) {
+        DeviceShape s{256, 160 * 1024};
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, d) == hipSuccess) {
+            if (pr.multiProcessorCount > 0) s.cus = pr.multiProcessorCount;
+            if (pr.maxSharedMemoryPerMultiProcessor > 0) s.lds_per_cu = (int)pr.maxSharedMemoryPerMultiProcessor;
+        }
+        cache[d] = s;
+        have[d] = true;
+    }
+    return cache[d];
+}
+
+static bool use_quad_kernel(KernelChoice c, int mode, int N, int B, bool polish, int lds_per_cu = 160 * 1024)
 {
     if (mode != NMPC_MODE_RTI || nmpcw::waves_per_instance(N) != 1 || c == KERNEL_WAVE) return false;
     if (c == KERNEL_QUAD) return true;
@@ -586,7 +644,7 @@ static bool use_quad_kernel(KernelChoice c, int mode, int N, int B, bool polish)
     // polish on, the one-instance kernel needs a third fewer factorisations and is the faster one
     if (polish) return false;
     const size_t qbytes = (size_t)nmpcq::quad_lds_doubles(N) * sizeof(double);
-    return B >= 8192 && N >= 32 && 2 * qbytes <= 160 * 1024;
+    return B >= 8192 && N >= 32 && 2 * qbytes <= (size_t)lds_per_cu;
 }
 
 // Order kernel (optional: `hist` = iteration counts of the previous solve, `order` = its output) and
@@ -601,16 +659,20 @@ static int launch_solve(KernelArgs &a, int mode, hipStream_t stream, const int *
         HIP_TRY(hipGetLastError());
         a.order = order;
     }
-    if (use_quad_kernel(choice, mode, N, B, a.pb.polish != 0)) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const DeviceShape shape = device_shape(dev);
+    if (use_quad_kernel(choice, mode, N, B, a.pb.polish != 0, shape.lds_per_cu)) {
         // SQP-RTI up to N = 63: workgroups of four waves, each wave a slot that draws instances from a
         // launch-wide ticket queue (nmpc_quad_solver.h); no more workgroups than can be resident at once
         // are needed -- later ones would find the queue empty
         if (!a.queue) return NMPC_EINVAL;
         HIP_TRY(hipMemsetAsync(a.queue, 0, 256, stream));
         const size_t qbytes = (size_t)nmpcq::quad_lds_doubles(N) * sizeof(double);
-        const int per_cu = (int)(160 * 1024 / qbytes) < 2 ? (int)(160 * 1024 / qbytes) : 2;   // five waves each: two per CU
+        const int fit = (int)((size_t)shape.lds_per_cu / qbytes);
+        const int per_cu = fit < 2 ? fit : 2;       // four waves of up to 256 VGPRs each: two workgroups per CU
         int wgs = (B + nmpcq::QI - 1) / nmpcq::QI;
-        const int resident = 256 * (per_cu < 1 ? 1 : per_cu);
+        const int resident = shape.cus * (per_cu < 1 ? 1 : per_cu);
         if (wgs > resident) wgs = resident;
         hipLaunchKernelGGL(nmpc_quad_kernel, dim3(wgs), dim3(QUAD_THREADS), qbytes, stream, a);
         HIP_TRY(hipGetLastError());
@@ -950,6 +1012,10 @@ int nmpc_destroy(nmpc_handle *h)
     int rc = NMPC_OK;
     for (void *p : ptrs)
         if (p && !hip_ok(hipFree(p), "hipFree")) rc = NMPC_EHIP;
+    for (void *p : {(void *)h->d_xs, (void *)h->d_us})
+        if (p && !hip_ok(hipFree(p), "hipFree")) rc = NMPC_EHIP;
+    for (void *p : {(void *)h->h_px, (void *)h->h_pu})
+        if (p && !hip_ok(hipHostFree(p), "hipHostFree")) rc = NMPC_EHIP;
     if (!hip_ok(hipStreamDestroy(h->stream), "hipStreamDestroy")) rc = NMPC_EHIP;
     delete h;
     return rc;
@@ -1013,7 +1079,19 @@ int nmpc_set_bounds(nmpc_handle *h, const double *bnd, int B)
 int nmpc_set_horizons(nmpc_handle *h, const int32_t *N, int B)
 {
     if (!h) return NMPC_EINVAL;
-    if (!N) { h->per_instance_N = false; return NMPC_OK; }
+    if (!N) {
+        // every instance uses cfg.N again -- also in the table, so that a later call naming fewer instances
+        // does not bring stale horizons back for the others
+        h->per_instance_N = false;
+        if (h->d_horizons) {
+            HIP_TRY(hipSetDevice(h->device));
+            std::vector<int> all;
+            try { all.assign((size_t)h->capacity, h->cfg.N); } catch (...) { return NMPC_ENOMEM; }
+            HIP_TRY(hipMemcpyAsync(h->d_horizons, all.data(), sizeof(int) * all.size(), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+        return NMPC_OK;
+    }
     if (B <= 0 || B > h->capacity) return NMPC_EINVAL;
     for (int i = 0; i < B; ++i)
         if (N[i] < 1 || N[i] > h->cfg.N) {
@@ -1118,16 +1196,26 @@ int nmpc_solve_static(const nmpc_config *cfg, int device, void *stream, int B, i
     StaticScratch *sc = nullptr;
     int rc = static_scratch(device, &sc);
     if (rc != NMPC_OK) return rc;
-    if (!g_static_lds_raised[device][cfg->N]) {
-        rc = raise_lds_limit(cfg->N);
-        if (rc != NMPC_OK) return rc;
-        g_static_lds_raised[device][cfg->N] = true;
+    {
+        std::lock_guard<std::mutex> lk(g_static_mu);
+        if (!g_static_lds_raised[device][cfg->N]) {
+            rc = raise_lds_limit(cfg->N);
+            if (rc != NMPC_OK) return rc;
+            g_static_lds_raised[device][cfg->N] = true;
+        }
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // the array keeps the previous call's contents: flags are rewritten for this batch, and a cold
-    // batch has no history worth ordering by (zero = identity order)
-    HIP_TRY(hipMemsetAsync(sc->reset, cold ? 1 : 0, (size_t)B, st));
-    if (!cold) HIP_TRY(hipMemcpyAsync(sc->hist, d_ipm_iters, sizeof(int) * (size_t)B, hipMemcpyDeviceToDevice, st));
+    // the array keeps the previous call's contents: flags are rewritten for this batch -- all cold, or, on a
+    // warm call, cold where the caller's d_status says the previous solve of the instance failed (what the
+    // kernels of nmpc_solve leave in the handle's flags) -- and a cold batch has no history worth ordering
+    // by (zero = identity order)
+    if (cold) {
+        HIP_TRY(hipMemsetAsync(sc->reset, 1, (size_t)B, st));
+    } else {
+        HIP_TRY(hipMemcpyAsync(sc->hist, d_ipm_iters, sizeof(int) * (size_t)B, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(nmpc_reset_from_status_kernel, dim3((B + 255) / 256), dim3(256), 0, st, sc->reset, d_status, B, sc->hist);
+        HIP_TRY(hipGetLastError());
+    }
     KernelArgs a;
     fill_problem(*cfg, NMPC_MODE_RTI, 1, 0.0, a.pb);
     a.B = B;
@@ -1170,38 +1258,65 @@ int nmpc_sync(nmpc_handle *h)
     return NMPC_OK;
 }
 
+// x / u of instances 0..B-1 into the handle's pinned host buffers (enqueued; the caller synchronises)
+static int stage_trajectories(nmpc_handle *h, int B)
+{
+    const size_t cap = (size_t)h->capacity, N = (size_t)h->cfg.N, N1 = N + 1;
+    if (!h->d_xs) {
+        // all or nothing, once per handle
+        double *dx = nullptr, *du = nullptr, *px = nullptr, *pu = nullptr;
+        bool ok = hip_ok(hipMalloc((void **)&dx, sizeof(double) * cap * N1 * 6), "hipMalloc") &&
+                  hip_ok(hipMalloc((void **)&du, sizeof(double) * cap * N * 2), "hipMalloc") &&
+                  hip_ok(hipHostMalloc((void **)&px, sizeof(double) * cap * N1 * 6, hipHostMallocDefault), "hipHostMalloc") &&
+                  hip_ok(hipHostMalloc((void **)&pu, sizeof(double) * cap * N * 2, hipHostMallocDefault), "hipHostMalloc");
+        if (!ok) {
+            if (dx) (void)hipFree(dx);
+            if (du) (void)hipFree(du);
+            if (px) (void)hipHostFree(px);
+            if (pu) (void)hipHostFree(pu);
+            return NMPC_EHIP;
+        }
+        h->d_xs = dx; h->d_us = du; h->h_px = px; h->h_pu = pu;
+    }
+    const size_t n = (size_t)B * N1;
+    hipLaunchKernelGGL(nmpc_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_traj, B, (int)N,
+                       h->d_xs, h->d_us);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h->h_px, h->d_xs, sizeof(double) * n * 6, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->h_pu, h->d_us, sizeof(double) * (size_t)B * N * 2, hipMemcpyDeviceToHost, h->stream));
+    return NMPC_OK;
+}
+
 int nmpc_get(nmpc_handle *h, int B, double *x, double *u, int32_t *status, double *cost,
              int32_t *ipm_iters, int32_t *sqp_iters)
-try {
+{
     if (!h || B <= 0 || B > h->capacity) return NMPC_EINVAL;
     HIP_TRY(hipSetDevice(h->device));
     const size_t N = (size_t)h->cfg.N, N1 = N + 1;
     if (x || u) {
-        h->h_traj.resize((size_t)B * N1 * 8);
-        HIP_TRY(hipMemcpyAsync(h->h_traj.data(), h->d_traj, sizeof(double) * h->h_traj.size(),
-                               hipMemcpyDeviceToHost, h->stream));
+        const int rc = stage_trajectories(h, B);
+        if (rc != NMPC_OK) return rc;
     }
     if (status) HIP_TRY(hipMemcpyAsync(status, h->d_status, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
     if (cost) HIP_TRY(hipMemcpyAsync(cost, h->d_cost, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
     if (ipm_iters) HIP_TRY(hipMemcpyAsync(ipm_iters, h->d_iters, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
     if (sqp_iters) HIP_TRY(hipMemcpyAsync(sqp_iters, h->d_sqp, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (x || u) {
-        const double *t = h->h_traj.data();
-        for (size_t b = 0; b < (size_t)B; ++b)
-            for (size_t k = 0; k < N1; ++k) {
-                const double *r = t + (b * N1 + k) * 8;
-                if (x) memcpy(x + (b * N1 + k) * 6, r, sizeof(double) * 6);
-                if (u && k < N) { u[(b * N + k) * 2] = r[6]; u[(b * N + k) * 2 + 1] = r[7]; }
-            }
-    }
+    if (x) memcpy(x, h->h_px, sizeof(double) * (size_t)B * N1 * 6);
+    if (u) memcpy(u, h->h_pu, sizeof(double) * (size_t)B * N * 2);
     return NMPC_OK;
-} catch (const std::bad_alloc &) {   // host containers: no exception may cross the C ABI
-    snprintf(g_err, sizeof(g_err), "nmpc_get: out of host memory");
-    return NMPC_ENOMEM;
-} catch (...) {
-    snprintf(g_err, sizeof(g_err), "nmpc_get: unexpected exception");
-    return NMPC_EINVAL;
+}
+
+int nmpc_get_view(nmpc_handle *h, int B, const double **x, const double **u)
+{
+    if (!h || !x || !u || B <= 0 || B > h->capacity) return NMPC_EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    const int rc = stage_trajectories(h, B);
+    if (rc != NMPC_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *x = h->h_px;
+    *u = h->h_pu;
+    return NMPC_OK;
 }
 
 int nmpc_get_controls(nmpc_handle *h, int B, double *ctrl)
@@ -1294,8 +1409,9 @@ int nmpc_get_world_path(nmpc_handle *h, int B, double *xy)
     return NMPC_OK;
 }
 
-int nmpc_closed_loop(nmpc_handle *h, int B, int steps, double dt_plant, double steering_ratio,
-                     double *world_state, const double *pitch_vref, double *trace, int32_t *n_failed)
+static int closed_loop_impl(nmpc_handle *h, int B, int steps, double dt_plant, double steering_ratio,
+                            double *world_state, const double *pitch_vref, const double *steer_meas,
+                            double *commands, double *trace, int32_t *n_failed)
 try {
     if (!h || !world_state || !pitch_vref || B <= 0 || B > h->capacity || steps < 1 || !h->d_track ||
         !(dt_plant > 0.0) || !(steering_ratio != 0.0))
@@ -1303,18 +1419,31 @@ try {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemcpyAsync(h->d_ws, world_state, sizeof(double) * 6 * (size_t)B, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->d_pv, pitch_vref, sizeof(double) * 2 * (size_t)B, hipMemcpyHostToDevice, h->stream));
+    // per-tick rows in and out (measured steering-wheel angles, published commands) go through d_xy, the
+    // un-rotation buffer: [cap][N+1][2] doubles, idle during the loop
+    double *d_row = h->d_xy, *d_cmd = h->d_xy + (size_t)h->capacity;
     int failed = 0;
     std::vector<int32_t> st;
     for (int s = 0; s < steps; ++s) {
-        // front-end -> one SQP-RTI iteration (warm start, no shift) -> actuation + plant, all on the
-        // handle's stream; no host round trip unless the caller asked for a trace
+        // (measurement ->) front-end -> one SQP-RTI iteration (warm start, no shift) -> actuation + plant,
+        // all on the handle's stream; no host round trip unless the caller asked for a trace
+        if (steer_meas) {
+            HIP_TRY(hipMemcpyAsync(d_row, steer_meas + (size_t)s * B, sizeof(double) * (size_t)B, hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(nmpc_measured_steering_kernel, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->d_ws, d_row, B,
+                               steering_ratio);
+            HIP_TRY(hipGetLastError());
+        }
         int rc = launch_frontend(h, B);
         if (rc != NMPC_OK) return rc;
         rc = nmpc_solve(h, B, NMPC_MODE_RTI, 1, 0.0);
         if (rc != NMPC_OK) return rc;
         hipLaunchKernelGGL(nmpc_plant_kernel, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->d_ws, h->d_pv, h->out_ctrl,
-                           B, dt_plant, 1.0 / h->cfg.wheelbase, steering_ratio);
+                           B, dt_plant, 1.0 / h->cfg.wheelbase, steering_ratio, steer_meas ? 1 : 0,
+                           commands ? d_cmd : (double *)nullptr);
         HIP_TRY(hipGetLastError());
+        if (commands)
+            HIP_TRY(hipMemcpyAsync(commands + (size_t)s * B * 2, d_cmd, sizeof(double) * 2 * (size_t)B,
+                                   hipMemcpyDeviceToHost, h->stream));
         if (trace)
             HIP_TRY(hipMemcpyAsync(trace + (size_t)s * B * 6, h->d_ws, sizeof(double) * 6 * (size_t)B,
                                    hipMemcpyDeviceToHost, h->stream));
@@ -1335,6 +1464,20 @@ try {
 } catch (...) {
     snprintf(g_err, sizeof(g_err), "nmpc_closed_loop: unexpected exception");
     return NMPC_EINVAL;
+}
+
+int nmpc_closed_loop(nmpc_handle *h, int B, int steps, double dt_plant, double steering_ratio,
+                     double *world_state, const double *pitch_vref, double *trace, int32_t *n_failed)
+{
+    return closed_loop_impl(h, B, steps, dt_plant, steering_ratio, world_state, pitch_vref, nullptr, nullptr, trace, n_failed);
+}
+
+int nmpc_closed_loop_measured(nmpc_handle *h, int B, int steps, double dt_plant, double steering_ratio,
+                              double *world_state, const double *pitch_vref, const double *steer_meas,
+                              double *commands, double *trace, int32_t *n_failed)
+{
+    if (!steer_meas) return NMPC_EINVAL;
+    return closed_loop_impl(h, B, steps, dt_plant, steering_ratio, world_state, pitch_vref, steer_meas, commands, trace, n_failed);
 }
 
 // ---- multi-GPU: all-gather of the control records over RCCL.  RCCL is bound at

@@ -157,7 +157,8 @@ constexpr int X_SIZE = 168;
 constexpr int X_POLICY = 8;
 constexpr int waves_per_instance(int N) { return N + 1 <= 64 ? 1 : 2; }
 constexpr int lds_doubles_st(int st, int N) { return (N + 1) * st + X_SIZE + (waves_per_instance(N) > 1 ? X_POLICY : 0); }
-// instances that fit into a CU: 160 KB of LDS (allocated in 512-byte steps), 8 waves at up to 256 VGPRs
+// instances that fit into a CU of the MI355X this layout choice is tuned for: 160 KB of LDS (allocated in
+// 512-byte steps), 8 waves at up to 256 VGPRs (on another part the choice stays correct, only its tuning is off)
 constexpr int instances_per_cu(int st, int N)
 {
     const int bytes = (lds_doubles_st(st, N) * 8 + 511) / 512 * 512;
@@ -537,7 +538,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
         // number of corrections the interior-point iteration goes on where it was (its state is not touched).
         // Working sets are packed two bits per pair q (u0,u1,delta,thr): 0 free, 1 at lower, 2 at upper.
         int pol = 0, tries_left = 0, n_pol = 0;    // (uniform) this pass of the loop is an active-set solve; solves so far
-        int wsp = 0, wsprev = -1;                  // working set, last classification attempted
+        int wsp = 0, wsprev = -1, cls = 0;         // working set, last classification attempted, current classification
         int fixm = 0;                              // inputs of this stage fixed by a pin (bit 0: u0, bit 1: u1)
         double gscale = 1.0;                       // size of the gradient entries the multipliers are differences of
         bool polished = false;
@@ -581,13 +582,8 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
             // stalled: the step lengths have stayed tiny (infeasible or hopelessly started QP)
             if (pb.stall_iter > 0 && it >= pb.stall_iter && lin_scale > pb.stall_lin) { qp_status = 4; break; }
             if (pb.polish && it > 0 && mu <= pb.polish_mu) {
-                // classify every pair by its slack against its multiplier; attempt when the classification is new
-                int cls = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (mq[q] && tl[q] < ll[q]) cls |= 1 << (2 * q);
-                    else if (mq[q] && tu[q] < lu[q]) cls |= 2 << (2 * q);
-                }
+                // every pair classified by its slack against its multiplier as the last step predicted them at
+                // full length (cls, from E-C); attempt when the classification is new
                 if (w.max(cls != wsprev ? 1.0 : 0.0) != 0.0) { wsprev = cls; wsp = cls; pol = 1; tries_left = pb.polish_tries; }
             }
             }
@@ -1133,6 +1129,14 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                         dlu[q] = mq[q] ? (ctu * itu - lu[q] - lu[q] * itu * dtu[q]) : 0.0;
                         r_loc = fmax(r_loc, fmax(-dtl[q] * itl, -dtu[q] * itu));
                         r_loc = fmax(r_loc, mq[q] ? fmax(-dll[q] * w.rcp(ll[q]), -dlu[q] * w.rcp(lu[q])) : 0.0);
+                    }
+                    // active-set classification for the polish: where the full step (not cut back to stay interior)
+                    // would leave slack below multiplier -- the limit each pair is heading for
+                    cls = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (mq[q] && tl[q] + dtl[q] < ll[q] + dll[q]) cls |= 1 << (2 * q);
+                        else if (mq[q] && tu[q] + dtu[q] < lu[q] + dlu[q]) cls |= 2 << (2 * q);
                     }
                     const double a_max = w.rcp(w.max(r_loc));
                     const double tau = fmax(pb.tau, 1.0 - mu_aff);

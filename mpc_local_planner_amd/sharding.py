@@ -65,6 +65,10 @@ class HostSync:
     def launch(self, produced_token, fn):
         return fn(True)          # fn(async_op) -> work handle
 
+    def finish(self, token):
+        """Block the host until the collective behind `token` has completed."""
+        token.wait()
+
 
 class CudaSync:
     """Ordering primitives for device tensors: the producer (the solver) runs on `solve_stream`, the
@@ -92,6 +96,11 @@ class CudaSync:
             done = self.torch.cuda.Event()
             done.record(self.comm_stream)
         return done
+
+    def finish(self, token):
+        """Block the host until the collective behind `token` has completed (Event.wait() would only make
+        the current stream wait: the host must not read the gathered block before this returns)."""
+        token.synchronize()
 
 
 class ControlGatherPipeline:
@@ -139,10 +148,7 @@ class ControlGatherPipeline:
             tok = self.tokens[i]
             if tok is None:
                 continue
-            if hasattr(tok, "wait"):
-                tok.wait()
-            else:
-                tok.synchronize()
+            self.sync.finish(tok)
             self.tokens[i] = None
 
     def last(self):

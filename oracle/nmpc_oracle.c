@@ -606,14 +606,14 @@ int orc_qp_solve(const orc_config *cfg, const orc_qp *qp, double *hint, double *
 {
     const int N = qp->N;
     const size_t nb = (size_t)N * NB;
-    double *mem = orc_ws_get(0, (size_t)(N + 1) * NZ * 4 + nb * 17 + (size_t)N * (64 + 8 + 6 + 8 + 12 + 4 + 2));
+    double *mem = orc_ws_get(0, (size_t)(N + 1) * NZ * 4 + nb * 18 + (size_t)N * (64 + 8 + 6 + 8 + 12 + 4 + 2));
     if (!mem) return 4;
     double *z = mem, *dz = z + (N + 1) * NZ, *dzc = dz + (N + 1) * NZ, *zp = dzc + (N + 1) * NZ;
     double *tl = zp + (N + 1) * NZ, *tu = tl + nb, *ll = tu + nb, *lu = ll + nb;
     double *dtl = lu + nb, *dtu = dtl + nb, *dll = dtu + nb, *dlu = dll + nb;
     double *lo = dlu + nb, *up = lo + nb, *msk = up + nb, *rtl = msk + nb, *rtu = rtl + nb;
-    double *sm = rtu + nb, *wsd = sm + nb, *ws0d = wsd + nb, *wspd = ws0d + nb;   /* polish: multipliers, working sets */
-    double *Hd = wspd + nb, *G = Hd + (size_t)N * 64, *rb = G + (size_t)N * 8, *dG = rb + (size_t)N * 6;
+    double *sm = rtu + nb, *wsd = sm + nb, *ws0d = wsd + nb, *wspd = ws0d + nb, *clsd = wspd + nb;   /* polish: multipliers, working sets */
+    double *Hd = clsd + nb, *G = Hd + (size_t)N * 64, *rb = G + (size_t)N * 8, *dG = rb + (size_t)N * 6;
     ric_ws w;
     w.N = N;
     w.K = dG + (size_t)N * 8;
@@ -638,7 +638,7 @@ int orc_qp_solve(const orc_config *cfg, const orc_qp *qp, double *hint, double *
         }
     double lin_scale = 1.0, mu = 0.0;
     /* ---- active-set polish (see orc_ws_solve): working sets as int arrays carved from the work area */
-    int *ws = (int *)wsd, *ws0 = (int *)ws0d, *wsprev = (int *)wspd;
+    int *ws = (int *)wsd, *ws0 = (int *)ws0d, *wsprev = (int *)wspd, *cls = (int *)clsd;
     int n_pol = 0, polished = 0;
     for (size_t q = 0; q < nb; ++q) {
         /* the active set the iterate suggests: a bounded quantity sitting on its bound (the previous QP of a
@@ -668,13 +668,12 @@ int orc_qp_solve(const orc_config *cfg, const orc_qp *qp, double *hint, double *
         if (cfg->ipm_stall_iter > 0 && it >= cfg->ipm_stall_iter && lin_scale > cfg->ipm_stall_lin) { status = 4; break; }
 
         if (cfg->polish && it > 0 && mu <= cfg->polish_mu) {
-            /* classify every pair by its slack against its multiplier; attempt when the classification is new */
+            /* every pair classified by its slack against its multiplier, both as the last step predicted them
+               at full length (see below); attempt when the classification is new */
             int same = 1;
             for (size_t q = 0; q < nb; ++q) {
-                int c = 0;
-                if (msk[q] != 0.0) { if (tl[q] < ll[q]) c = -1; else if (tu[q] < lu[q]) c = 1; }
-                ws[q] = c;
-                if (c != wsprev[q]) same = 0;
+                ws[q] = cls[q];
+                if (ws[q] != wsprev[q]) same = 0;
             }
             if (!same) {
                 memcpy(wsprev, ws, nb * sizeof(int));
@@ -763,6 +762,16 @@ int orc_qp_solve(const orc_config *cfg, const orc_qp *qp, double *hint, double *
             }
         const double tau = fmax(cfg->ipm_tau, 1.0 - mu_aff);
         const double alpha = fmin(1.0, tau * a_max);
+        /* active-set classification for the polish: where the full step (not cut back to stay interior) would
+           leave slack below multiplier.  One step ahead of comparing the iterate's own pairs, and the limit the
+           pair is heading for rather than where the step length stopped it. */
+        for (size_t q = 0; q < nb; ++q) {
+            cls[q] = 0;
+            if (msk[q] != 0.0) {
+                if (tl[q] + dtl[q] < ll[q] + dll[q]) cls[q] = -1;
+                else if (tu[q] + dtu[q] < lu[q] + dlu[q]) cls[q] = 1;
+            }
+        }
         for (int k = 0; k <= N; ++k)
             for (int i = 0; i < NZ; ++i) z[k * NZ + i] += alpha * dz[k * NZ + i];
         for (size_t q = 0; q < nb; ++q) {

@@ -9,6 +9,7 @@
 #include <cmath>
 
 #include "mpc_local_planner_amd/PathTrackingSys.hpp"
+#include "mpc_local_planner_amd/utilities.hpp"
 
 int main(int argc, char **argv) {
     if (argc < 3) return 2;
@@ -44,13 +45,9 @@ int main(int argc, char **argv) {
         printf("\n");
         if (r.mpcHorizon.size() != (size_t)N || r.u0.deltaDot != r.mpcHorizon[0].u.deltaDot) return 3;
     }
-    // PathTrackingSys on an ellipse-like track: state on the track -> world-frame horizon
+    // PathTrackingSys on util::getTestTrack (config 1: tests/testMpc.h:13 on the reference's track): state on the track -> world-frame horizon
     {
-        std::vector<mpc::Point> track;
-        for (int i = 0; i < 400; ++i) {
-            const double th = 2 * M_PI * i / 400.0;
-            track.emplace_back(40 * cos(th), 20 * sin(th) + 20 / 1.2 * sin(3 * th));
-        }
+        const std::vector<mpc::Point> track = mpc::util::getTestTrack();   // the reference's own demo track (401 points)
         for (auto &pt : track) printf("track %.17g %.17g\n", pt.x, pt.y);
         mpc::PathTrackingSys sys{track, N};
         const mpc::State car{41, 0, M_PI / 2, 5, 0, 0};          // tests/testMpc.h:13
@@ -91,6 +88,22 @@ int main(int argc, char **argv) {
         auto r = sq.solve(states[0], params[0]);
         printf("sqpfile %d %d %d", (int)r.success, sq.horizon(), sq.runParams().mode);
         for (auto &o : r.mpcHorizon)
+            printf(" %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g", o.x.x, o.x.y, o.x.psi, o.x.vel, o.x.delta,
+                   o.x.throttle, o.u.deltaDot, o.u.throttleDot);
+        printf("\n");
+    }
+    // reInit after a failure with a FINITE state (src/AcadosSolver.cpp:56-59, 8-13): the guess is built from
+    // the state of the failing call, and the next solve starts from it whatever it measures.  An
+    // interior-point limit of 3 iterations makes every solve fail with status 4 (the step is still taken).
+    if (B >= 2) {
+        nmpc_config c3;
+        nmpc_default_config(&c3, N, 0.35);
+        c3.ipm_max_iter = 3;
+        mpc::Acados::PathTracking lim{states[0], c3};
+        auto r1 = lim.solve(states[0], params[0]);
+        auto r2 = lim.solve(states[1], params[0]);
+        printf("reinit %d %d", (int)r1.success, (int)r2.success);
+        for (auto &o : r2.mpcHorizon)
             printf(" %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g", o.x.x, o.x.y, o.x.psi, o.x.vel, o.x.delta,
                    o.x.throttle, o.u.deltaDot, o.u.throttleDot);
         printf("\n");

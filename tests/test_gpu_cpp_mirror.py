@@ -32,7 +32,7 @@ def test_cpp_mirror_single_and_batch(tmp_path):
     nb = 0
     single = []
     track = np.array([ln.split()[1:] for ln in lines if ln.startswith("track ")], dtype=float)
-    assert track.shape == (400, 2)
+    assert track.shape == (401, 2) and np.array_equal(track, orc.test_track())    # util::getTestTrack, fp accumulation included
     seen = set()
     pts_first = None
     for ln in lines:
@@ -82,11 +82,24 @@ def test_cpp_mirror_single_and_batch(tmp_path):
                 h = np.array(t[4:], dtype=float).reshape(100, 8)
                 s = max(1.0, np.abs(xt).max())
                 assert np.abs(h[:, :6] - xt[:100]).max() <= 1e-6 * s and np.abs(h[:, 6:] - ut).max() <= 1e-6 * s
+        elif t[0] == "reinit":
+            # both solves fail (3 interior-point iterations); the second started from the guess reInit built
+            # from the FIRST call's state (x_k = that state, u_k = 0), not from its own measurement
+            assert (t[1], t[2]) == ("0", "0")
+            oc3 = orc.config_like(capi.default_config(N, 0.35, ipm_max_iter=3))
+            xt, ut = orc.init_guess(oc3, x0[0])
+            assert orc.rti(oc3, x0[1], p[0], xt, ut).status == 4
+            h = np.array(t[3:], dtype=float).reshape(N, 8)
+            s = max(1.0, np.abs(xt).max())
+            assert np.abs(h[:, :6] - xt[:N]).max() <= 1e-9 * s and np.abs(h[:, 6:] - ut).max() <= 1e-9 * s
+            xc, uc = orc.init_guess(oc3, x0[1])                  # (the cold start from the second state differs)
+            orc.rti(oc3, x0[1], p[0], xc, uc)
+            assert np.abs(h[:, :6] - xc[:N]).max() > 1e-3
         elif t[0] == "single":
             assert t[2] == "1"
             single.append(np.array(t[4:], dtype=float).reshape(N, 8))
     assert nb == B and len(single) == 3
-    assert {"pts", "failed", "pts2", "sqpfile"} <= seen
+    assert {"pts", "failed", "pts2", "sqpfile", "reinit"} <= seen
     # single-instance protocol: cold call, then two warm calls without shift
     x1, u1 = xo[0:1].copy(), uo[0:1].copy()
     for call in range(3):

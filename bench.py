@@ -35,7 +35,10 @@ HBM_PEAK_GBPS = 8000.0
 # cannot be read from inside this process): 2 x FETCH_SIZE (gfx950 tallies 128-B requests as 64 B;
 # the factor is calibrated for wide streaming reads only, so this is an upper bound) + WRITE_SIZE,
 # both in KiB as rocprofv3 reports them.
-PMC_SUMMARY = os.path.join(ROOT, "profiles", os.environ.get("NMPC_PMC_ROUND", "r2"), "pmc_summary.json")
+PMC_ROUND = os.environ.get("NMPC_PMC_ROUND", "r3")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", PMC_ROUND, "pmc_summary.json")
+PMC_SOURCE = f"profiles/{PMC_ROUND}/pmc_summary.json (rocprofv3 PMC passes of tools/pmc_passes.sh on the same workload, " \
+             "committed with the build they were taken from; not measured in this run)"
 N_CU, CLOCK_HZ = 256, 2.4e9      # MI355X_MICROARCH.md chip-level parameters
 N_INPUT_SETS = 4
 
@@ -66,9 +69,12 @@ def pmc_lds_cycles_per_solve():
         return None
 
 
-def flops_per_solve(N, n_ipm):
-    # F(N, n_ipm) = N (1400 + 2200 n_ipm + 16)
-    return N * (1400.0 + 2200.0 * n_ipm + 16.0)
+def flops_per_solve(N, n_fact, polish=True):
+    # F(N, n) = N (1400 + 2200 n + 16) with n interior-point iterations.  With the active-set
+    # polish n counts factorisations -- interior-point iterations and active-set solves -- and a solve is
+    # priced like the cheaper of the two: factor sweep 1350 + two forward and one backward vector sweep 580 +
+    # element-wise work ~170 = 2100 (an interior-point iteration: 2200), so the figure errs low.
+    return N * (1400.0 + (2100.0 if polish else 2200.0) * n_fact + 16.0)
 
 
 def bytes_per_solve(N, warm):
@@ -407,12 +413,17 @@ def main():
                    "batch_per_gpu": B, "horizon": N, "parallelism": f"dp{world} (instances sharded, "
                    "RCCL all-gather of control records)" if world > 1 else "single GPU"},
         "mean_ipm_iters": n_ipm_cold, "converged_frac": ok_cold,
+        "qp": {"polish": int(solver.cfg.polish), "max_iters": int(g["ipm_iters"].max()),
+               "iters_hist": np.bincount(g["ipm_iters"], minlength=1).tolist(),
+               "note": "iterations = factorisations per QP: interior-point iterations + active-set solves "
+                       "(nmpc_config.polish; 0 = interior point to its own termination test, as rounds 1-2)"},
         "step_ms": {"median": float(np.median(kms_main)), "min": float(np.min(kms_main)), "mean": kernel_ms,
                     "max": float(np.max(kms_main)), "n": len(kms_main),
                     "note": "HIP events on the solver's stream around each step's launches"},
         "parity": "vs CPU restatement (oracle/); acados parity unpinned",
     }
-    fl = flops_per_solve(N, n_ipm_cold) * B
+    polish_on = bool(solver.cfg.polish)
+    fl = flops_per_solve(N, n_ipm_cold, polish_on) * B
     by = bytes_per_solve(N, False) * B
     tf = fl / (kernel_ms * 1e-3) / 1e12
     lds_cyc = pmc_lds_cycles_per_solve() if (B == 4096 and N == 40) else None
@@ -423,7 +434,8 @@ def main():
         "note": "fp64 vector-FMA peak (= the dense fp64 MFMA peak, 78.6 TFLOP/s); the kernel has no MFMA-shaped work "
                 "(per-instance matrices are 6x6..9x9) and is bound by instruction issue on the serial Riccati "
                 "recursions and the LDS pipe, see 'lds' and DESIGN.md section 5; the HBM view is in 'hbm'",
-        "kernel_ms": kernel_ms, "flops_per_solve": flops_per_solve(N, n_ipm_cold),
+        "kernel_ms": kernel_ms, "flops_per_solve": flops_per_solve(N, n_ipm_cold, polish_on),
+        "traffic_source": PMC_SOURCE,
         "peak_measured_fma64": FP64_FMA_MEASURED_TFLOPS,
         "hbm": {"bound": "hbm", "achieved": by / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": by / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
@@ -434,13 +446,17 @@ def main():
         out["roofline"]["lds"] = {"bound": "lds_pipe", "lds_busy_cycles_per_solve": lds_cyc,
                                   "ceiling_solves_per_s": ceiling, "achieved_solves_per_s": B / (kernel_ms * 1e-3),
                                   "frac": B / (kernel_ms * 1e-3) / ceiling,
-                                  "note": "SQ_LDS_IDX_ACTIVE per solve (profiles/) -> 256 CUs x 2.4 GHz / cycles"}
+                                  "note": "SQ_LDS_IDX_ACTIVE per solve -> 256 CUs x 2.4 GHz / cycles", "source": PMC_SOURCE}
     out["warm"] = {"value": total_solves / dt_warm, "ms_per_step": 1e3 * dt_warm / args.steps,
                    "kernel_ms": float(np.mean(kms_warm)), "kernel_ms_median": float(np.median(kms_warm)),
                    "mean_ipm_iters": n_ipm_warm,
                    "note": "warm-started RTI calls; inputs move by 3 % of the spread between calls"}
     if dt_nogather:
-        out["multi_gpu"] = {"with_gather": value, "without_gather": total_solves / dt_nogather}
+        out["multi_gpu"] = {"with_gather": value, "without_gather": total_solves / dt_nogather,
+                            "dist_world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                            "gathered_block_shape": [world, B, 6],
+                            "note": "one RCCL all-gather of the 48-byte control records per step, on a side stream, "
+                                    "overlapped with the next solve; every rank checked its own block of the last one"}
     if rank == 0 and world == 1:
         # launch ordering off (a handle created under NMPC_SCHEDULE=0): same cold steps
         os.environ["NMPC_SCHEDULE"] = "0"
@@ -483,9 +499,16 @@ def main():
         for _ in range(reps):
             solver.set_x0(xh); solver.set_params(ph); solver.reset(None, B); solver.solve(B); solver.get(B)
         dt_f = (time.perf_counter() - t0) / reps
-        out["pcie_inclusive"] = {"controls_only_solves_per_s": B / dt_c, "full_trajectories_solves_per_s": B / dt_f,
-                                 "note": "host x0/p in (nmpc_set_x0/params), cold solve, control records (48 B) or full "
-                                         "trajectories (2.6 KB per instance, repacked on the host) out; synchronous calls"}
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            solver.set_x0(xh); solver.set_params(ph); solver.reset(None, B); solver.solve(B); solver.get_view(B)
+        dt_v = (time.perf_counter() - t0) / reps
+        out["pcie_inclusive"] = {"controls_only_solves_per_s": B / dt_c, "full_trajectories_solves_per_s": B / dt_v,
+                                 "full_trajectories_copied_solves_per_s": B / dt_f,
+                                 "note": "host x0/p in (nmpc_set_x0/params), cold solve, then out: control records (48 B "
+                                         "per instance), or full trajectories (2.6 KB per instance: x / u split on the "
+                                         "device, one DMA each into the handle's pinned host memory) read in place "
+                                         "(nmpc_get_view) or copied on into caller arrays (nmpc_get); synchronous calls"}
     if rank == 0 and world == 1 and not args.no_extras:
         out["extras"] = extras(capi, sc, hip, N)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -24,7 +24,6 @@ def main():
     per_launch = float(sys.argv[3]) if len(sys.argv) > 3 else 4096.0
     skip = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     out = {}
-    meta = None
     for dp, _, files in os.walk(root):
         for f in files:
             if not f.endswith("counter_collection.csv"):
@@ -34,9 +33,6 @@ def main():
                 for row in csv.DictReader(fh):
                     if kern not in row["Kernel_Name"]:
                         continue
-                    if meta is None:
-                        meta = {k: row[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size",
-                                                    "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count") if k in row}
                     vals[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
             for name, d in vals.items():
                 keep = [d[k] for k in sorted(d, key=int)][skip:]        # dispatch order; warm-ups dropped
@@ -56,7 +52,9 @@ def main():
                 srt = sorted(ms)
                 out["kernel_ms"] = {"launches": len(ms), "mean": sum(ms) / len(ms), "median": srt[len(srt) // 2],
                                     "min": srt[0], "max": srt[-1]}
-    json.dump({"_kernel_meta": meta, **out}, sys.stdout, indent=1)
+    # (rocprofv3's per-dispatch metadata -- VGPR_Count, LDS_Block_Size ... -- is not reported: it disagrees with the
+    # code object on this image; registers, scratch and LDS are in profiles/<round>/kernel_resources.txt)
+    json.dump(out, sys.stdout, indent=1)
     print()
 
 

@@ -731,9 +731,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 // active-set solve: the pins of the stage, (kap0, nu0) and (kap1, nu1): kap = 1 free input, else
                 // du_a = kap * dx_s + nu (s = delta for u0, thr for u1); selectors of this lane's row i and column j
                 const double *tpin = last + I_GAM01;
-                const double sj6 = f2j == 6 ? 1.0 : 0.0, sj7 = f2j == 7 ? 1.0 : 0.0, sj8 = f2j == 8 ? 1.0 : 0.0;
-                const double si6 = f2i == 6 ? 1.0 : 0.0, si7 = f2i == 7 ? 1.0 : 0.0;
-                const bool jcol = f2j <= 8;     // (lanes 44,45 carry unit columns, not columns of Ht)
+                const int pij = w.opaque(f2i | (f2j << 4));     // (row, column) of this lane, one register for the stage
                 // phase 2 store of the two input rows (pairs (Ht[0][j], Ht[1][j])), phase 3 loads/stores
                 double *const pHw = (f2on && f2i < 2) ? xa + X_HU + 2 * f2j + f2i : xa + X_DUM;
                 const double *const pHj = xa + X_HU + 2 * f2j;
@@ -806,9 +804,11 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                         const bool f0 = c.pin0.x <= 0.5, f1 = c.pin1.x <= 0.5;
                         const double k0 = f0 ? c.pin0.x : 0.0, n0 = f0 ? c.pin0.y : 0.0;
                         const double k1 = f1 ? c.pin1.x : 0.0, n1 = f1 ? c.pin1.y : 0.0;
-                        t0j = k0 * sj6 + n0 * sj8;
-                        t1j = k1 * sj7 + n1 * sj8;
-                        const double t0i = k0 * si6, t1i = k1 * si7;
+                        const int pi_ = pij & 15, pj_ = pij >> 4;
+                        const bool jcol = pj_ <= 8;     // (lanes 44,45 carry unit columns, not columns of Ht)
+                        t0j = pj_ == 6 ? k0 : pj_ == 8 ? n0 : 0.0;
+                        t1j = pj_ == 7 ? k1 : pj_ == 8 ? n1 : 0.0;
+                        const double t0i = pi_ == 6 ? k0 : 0.0, t1i = pi_ == 7 ? k1 : 0.0;
                         Hvp = Hv + t0i * hj.x + t0j * hi.x + t0i * t0j * H00 + t1i * hj.y + t1j * hi.y + t1i * t1j * H11 +
                               (t0i * t1j + t1i * t0j) * H01;
                         hjx = (f0 && jcol) ? 0.0 : hj.x + t1j * H01;

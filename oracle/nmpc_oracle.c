@@ -677,7 +677,9 @@ int orc_qp_solve(const orc_config *cfg, const orc_qp *qp, double *hint, double *
             }
             if (!same) {
                 memcpy(wsprev, ws, nb * sizeof(int));
-                if (polish_attempt(cfg, qp, lo, up, msk, ws, cfg->polish_tries, z, zp, sm, &n_pol) == 1) { polished = 1; break; }
+                const int pr = polish_attempt(cfg, qp, lo, up, msk, ws, cfg->polish_tries, z, zp, sm, &n_pol);
+                if (getenv("ORC_TRACE")) fprintf(stderr, "it %2d mu %.3e polish -> %d (solves so far %d)\n", it, mu, pr, n_pol);
+                if (pr == 1) { polished = 1; break; }
             }
         }
 

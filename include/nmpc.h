@@ -230,7 +230,8 @@ int nmpc_closed_loop_measured(nmpc_handle *h, int B, int steps, double dt_plant,
  *   cold != 0   : start from x_k = x0, u_k = 0 (nmpc_reset); cold == 0: warm start from d_traj as it is
  *   inputs  (device): d_x0[B][6], d_p[B][6], d_W[B][7] or NULL, d_bnd[B][8] or NULL (NULL = cfg's values)
  *   in/out  (device): d_traj[B][N+1][8] iterate per node X,Y,psi,v,delta,thr,u0,u1 (nmpc_device_ptr(h, 1)
- *                     layout); d_ipm_iters int32[B] (read when cold == 0: previous counts order the launch)
+ *                     layout; node N has no input: its u0 slot carries the solver's warm-start hint from one
+ *                     call to the next -- leave it as the last call wrote it, or zero it); d_ipm_iters int32[B] (read when cold == 0: previous counts order the launch)
  *                     d_status int32[B] (read when cold == 0: an instance whose previous status is not 0
  *                     starts cold, as the handle's own flags make it in nmpc_solve and as the reference
  *                     re-initialises after every failure, src/AcadosSolver.cpp:56-59; written with the new status)
@@ -262,7 +263,8 @@ int nmpc_shard_range(int64_t total, int rank, int world, int64_t *begin, int64_t
 
 /* Device-side views for zero-copy consumers (RCCL all-gather of the control records,
  * timing with HIP events).  which: 0 control records [cap][6], 1 iterate [cap][N+1][8]
- * (X,Y,psi,v,delta,thr,u0,u1 per node), 2 status int32[cap]. */
+ * (X,Y,psi,v,delta,thr,u0,u1 per node; the u0 slot of node N is not an input but the warm-start hint of
+ * the QP polish, see nmpc_config.polish), 2 status int32[cap]. */
 void *nmpc_device_ptr(nmpc_handle *h, int which);
 void *nmpc_stream(nmpc_handle *h);       /* hipStream_t */
 int nmpc_capacity(const nmpc_handle *h);

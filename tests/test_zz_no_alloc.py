@@ -20,11 +20,13 @@ def _static(cfg, B, cold, x0, p, W, bnd, traj, ctrl, status, iters):
     return rc
 
 
-@pytest.mark.parametrize("sweep,B1", [(False, 2048), (True, 2048), (False, 9000)])
-def test_static_entry_matches_nmpc_solve_two_calls(sweep, B1):
-    """B1 = 9000: the first call runs on the four-slot kernel in both entry points (the library's choice
-    for N = 40 from 8192 instances on; its ticket counter lives in the static workspace too), the second,
-    smaller one on the one-instance kernel."""
+@pytest.mark.parametrize("sweep,B1,polish", [(False, 2048, 1), (True, 2048, 1), (False, 9000, 1), (False, 9000, 0)])
+def test_static_entry_matches_nmpc_solve_two_calls(sweep, B1, polish):
+    """The warm second call also exercises the polish's hint, which travels in the caller's iterate buffer.
+    B1 = 9000 with polish = 0: the first call runs on the four-slot kernel in both entry points (the
+    library's choice for N = 40 from 8192 instances on when the QP is solved by the interior point alone;
+    its ticket counter lives in the static workspace too), the second, smaller one on the one-instance
+    kernel."""
     import torch
     N, B2 = 40, 777
     dev = torch.device("cuda:0")
@@ -41,7 +43,7 @@ def test_static_entry_matches_nmpc_solve_two_calls(sweep, B1):
         bnd[:, 1] *= rng.uniform(0.5, 1.5, size=B1)
         bnd[:, 5] = -bnd[:, 1]
     # existing entry point
-    s = capi.BatchSolver(N=N, dt=0.35, capacity=B1)
+    s = capi.BatchSolver(N=N, dt=0.35, capacity=B1, polish=polish)
     if sweep:
         s.set_weights(W)
         s.set_bounds(bnd)

@@ -761,13 +761,23 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 StageData sdA, sdB;
                 sdA.t01 = ld2(tj); sdA.b01 = ld2(bj); sdA.u01 = ld2(ti);
                 sdA.t2 = tj[2]; sdA.b2 = bj[2]; sdA.u2 = ti[2]; sdA.tbv = *tb;
-                if (pol) { sdA.pin0 = ld2(tpin); sdA.pin1 = ld2(tpin + (I_GAM23 - I_GAM01)); }
                 // (POL: std::true_type for an active-set solve -- a second instantiation of the stage, so that the
-                // interior-point iterations carry none of the pin arithmetic)
+                // interior-point iterations carry none of the pin arithmetic.  In the one-wave kernels that
+                // instantiation runs with ONE register set, c and n the same object: each operand group is
+                // refilled for the next stage right after its last use in this one, still a phase ahead of its
+                // next use, and the stage's pins are loaded at its start for its own phase 3 -- two sets plus
+                // pins in flight do not fit in 256 registers beside the interior point's state, which must
+                // survive a rejected attempt.  The two-wave kernels keep two sets: their sweeping wave has a SIMD
+                // to itself, nothing hides a later load there, and the single set measured -5 % on config 4)
+                constexpr bool kOneSet = !W::kNeighbourLds;
+                if (pol && !kOneSet) { sdA.pin0 = ld2(tpin); sdA.pin1 = ld2(tpin + (I_GAM23 - I_GAM01)); }
                 auto factor_stage = [&](auto POL, const StageData &c, StageData &n) {
                     constexpr bool kPol = decltype(POL)::value;
                     const D2 r01 = ld2(pProw), r23 = ld2(pProw + 2), r45 = ld2(pProw + 4);
                     const double r6 = pProw[6];
+                    D2 pin0 = {1.0, 0.0}, pin1 = {1.0, 0.0};
+                    if (kPol && kOneSet) { pin0 = ld2(tpin); pin1 = ld2(tpin + (I_GAM23 - I_GAM01)); tpin -= ST; }
+                    if (kPol && !kOneSet) { pin0 = c.pin0; pin1 = c.pin1; }
                     w.sched_fence();
                     // phase 1: Mt[m][j] = Pt[m][0..5] . BAt[0..5][j] + p[m] [j == 8]
                     double accA = r6 * e8, accB = r01.y * c.t01.y;
@@ -780,15 +790,17 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     const D2 m01 = ld2(pMr), m23 = ld2(pMr + 2), m45 = ld2(pMr + 4);
                     // data of stage k-1 (at k = 0 this reads the pseudo-stage: valid memory, not used)
                     tj -= sTopJ; bj -= sBotJ; ti -= sTopI; tb -= sTab;
-                    n.t01 = ld2(tj); n.b01 = ld2(bj); n.u01 = ld2(ti);
-                    n.t2 = tj[2]; n.b2 = bj[2]; n.u2 = ti[2]; n.tbv = *tb;
-                    if (kPol) { tpin -= ST; n.pin0 = ld2(tpin); n.pin1 = ld2(tpin + (I_GAM23 - I_GAM01)); }
+                    n.t01 = ld2(tj); n.b01 = ld2(bj);
+                    n.t2 = tj[2]; n.b2 = bj[2];
+                    if (!(kPol && kOneSet)) { n.u01 = ld2(ti); n.u2 = ti[2]; n.tbv = *tb; }
+                    if (kPol && !kOneSet) { tpin -= ST; n.pin0 = ld2(tpin); n.pin1 = ld2(tpin + (I_GAM23 - I_GAM01)); }
                     w.sched_fence();
                     double HvA = fma(c.u01.x, m01.x, hconst + c.tbv), HvB = c.u01.y * m01.y;
                     HvA = fma(c.u2, m23.x, HvA);  HvB = fma(v01.x, m23.y, HvB);
                     HvA = fma(v01.y, m45.x, HvA); HvB = fma(v2, m45.y, HvB);
                     const double Hv = HvA + HvB;
                     *pHw = Hv;
+                    if (kPol && kOneSet) { w.sched_fence(); n.u01 = ld2(ti); n.u2 = ti[2]; n.tbv = *tb; }
                     // the 2x2 input block straight from its lanes (0: H00, 1: H01, 9: H11): its inverse is
                     // worked out while the input rows make their way through LDS
                     const double H00 = w.readlane(Hv, 0), H01 = w.readlane(Hv, 1), H11 = w.readlane(Hv, 9);
@@ -801,9 +813,9 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     if (kPol) {
                         // substitute the pinned inputs du_a = t_a . (dx, 1) into the stage's quadratic, then treat
                         // them as decoupled dummies (unit diagonal, zero row) in the elimination below
-                        const bool f0 = c.pin0.x <= 0.5, f1 = c.pin1.x <= 0.5;
-                        const double k0 = f0 ? c.pin0.x : 0.0, n0 = f0 ? c.pin0.y : 0.0;
-                        const double k1 = f1 ? c.pin1.x : 0.0, n1 = f1 ? c.pin1.y : 0.0;
+                        const bool f0 = pin0.x <= 0.5, f1 = pin1.x <= 0.5;
+                        const double k0 = f0 ? pin0.x : 0.0, n0 = f0 ? pin0.y : 0.0;
+                        const double k1 = f1 ? pin1.x : 0.0, n1 = f1 ? pin1.y : 0.0;
                         const int pi_ = pij & 15, pj_ = pij >> 4;
                         const bool jcol = pj_ <= 8;     // (lanes 44,45 carry unit columns, not columns of Ht)
                         t0j = pj_ == 6 ? k0 : pj_ == 8 ? n0 : 0.0;
@@ -841,11 +853,16 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                         factor_stage(std::false_type(), sdB, sdA);
                     }
                 } else {
+                    if (kOneSet) {
 #pragma unroll 1
-                    for (int k = N - 1; k >= 0; k -= 2) {
-                        factor_stage(std::true_type(), sdA, sdB);
-                        if (k == 0) break;
-                        factor_stage(std::true_type(), sdB, sdA);
+                        for (int k = N - 1; k >= 0; --k) factor_stage(std::true_type(), sdA, sdA);
+                    } else {
+#pragma unroll 1
+                        for (int k = N - 1; k >= 0; k -= 2) {
+                            factor_stage(std::true_type(), sdA, sdB);
+                            if (k == 0) break;
+                            factor_stage(std::true_type(), sdB, sdA);
+                        }
                     }
                 }
             }

@@ -33,17 +33,22 @@ def _err(g, xo, uo, sel=slice(None)):
                       np.abs(g["u"][sel] - uo).reshape(B, -1).max(1))
 
 
-def assert_parity(g, xo, uo, io=None, sel=slice(None), ok=None):
-    """Every instance within TOL_BAR; >= 99 % within TOL; the median within 1e-11.  The few in
-    between are QPs with a weakly active bound along a direction of very small curvature: there
-    the interior-point termination threshold (pairwise complementarity 1e-11), not round-off,
-    sets the accuracy, and the CPU lane emulator differs from the oracle by as much."""
+def assert_parity(g, xo, uo, io=None, sel=slice(None), ok=None, frac=1.0):
+    """Every instance within TOL_BAR and within TOL (1e-9 relative), the median within 1e-11: with the
+    active-set polish both sides end on the vertex of the same active set, so they differ by round-off.
+    frac < 1 is for the interior point run to its own termination test (polish = 0, the four-slot kernel):
+    there a QP with a weakly active bound along a direction of very small curvature is only as accurate as
+    the termination threshold (pairwise complementarity 1e-11), the CPU lane emulator differs from the
+    oracle by as much, and `frac` of the instances must be within TOL."""
     sc_ = _scale(xo, uo)
     e = _err(g, xo, uo, sel)
     if ok is not None:
         e = e[ok]
     assert e.max() <= TOL_BAR * sc_, e.max()
-    assert (e <= TOL * sc_).mean() >= 0.99 - 1.5 / len(e), np.sort(e)[-5:]   # (one outlier allowed in small batches)
+    if frac >= 1.0:
+        assert (e <= TOL * sc_).all(), np.sort(e)[-5:]
+    else:
+        assert (e <= TOL * sc_).mean() >= frac - 1.5 / len(e), np.sort(e)[-5:]   # (one outlier allowed in small batches)
     if io is not None:
         same = g["ipm_iters"][sel] == io
         if ok is not None:

@@ -226,7 +226,7 @@ def test_quad_kernel_matches_oracle(N, monkeypatch):
             xo, uo, so, io = orc.rti_batch(ocfg, x0, p, xo, uo, cold=(it == 0))
             assert (g["status"] == 0).all() and (so == 0).all()
             if B >= 64:
-                assert_parity(g, xo, uo, io)
+                assert_parity(g, xo, uo, io, frac=0.99)
             else:
                 assert (_err(g, xo, uo) <= 1e-9 * _scale(xo, uo)).all()
             assert (np.abs(g["ipm_iters"] - io) <= 1).all()

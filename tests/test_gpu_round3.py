@@ -355,3 +355,58 @@ def test_set_horizons_null_restores_the_handles_horizon_for_everyone():
         r = one.get(50)
         one.close()
         assert np.array_equal(g["x"][sel][:, :n + 1], r["x"]) and np.array_equal(g["u"][sel][:, :n], r["u"]), n
+
+
+def test_gather_pipeline_cuda_sync_single_rank_finish_blocks_the_host():
+    """ControlGatherPipeline with CudaSync (the bench's N > 1 path) on one rank over RCCL: every step's
+    gathered block equals the records of that step's solve, and finish() has really waited on the host --
+    all collectives' events are complete when it returns (an Event.wait() would only have queued a stream
+    wait), so the gathered block may be handed to code outside torch's streams."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from mpc_local_planner_amd import sharding
+    N, B, steps = 40, 512, 5
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29577"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
+        solve_stream = torch.cuda.ExternalStream(int(s.stream()), device=dev)
+        records = [torch.zeros(B * 6, dtype=torch.float64, device=dev) for _ in range(2)]
+        gathered = [torch.full((B * 6,), -1.0, dtype=torch.float64, device=dev) for _ in range(2)]
+        pipe = sharding.ControlGatherPipeline(records, gathered, sharding.CudaSync(solve_stream, dev))
+        want = []
+        seen = []
+        for k in range(steps):
+            x0, p = sc.config2(B, start=k * B)
+            s.set_x0(x0); s.set_params(p)
+            s.reset(None, B)
+            i = pipe.begin_step()
+            s.set_controls_device(records[i].data_ptr())
+            s.solve(B)
+            pipe.end_step()
+            seen.append(pipe.tokens[i])
+            if k >= steps - 2:
+                # (the handle's own record buffer is not written while a caller's buffer is set: expected
+                # values come from a second, plain solve of the same inputs below)
+                want.append((i, x0, p))
+        pipe.finish()
+        assert all(t.query() for t in seen), "finish() returned before the collectives had completed"
+        assert pipe.tokens == [None, None]
+        i_last, g_last = pipe.last()
+        assert i_last == want[-1][0]
+        got = {i: gathered[i].clone() for i in (0, 1)}
+        s.set_controls_device(None)
+        for i, x0, p in want:
+            s.set_x0(x0); s.set_params(p)
+            s.reset(None, B)
+            s.solve(B)
+            ref = s.get_controls(B)
+            assert np.array_equal(got[i].cpu().numpy().reshape(B, 6), ref)
+            assert np.array_equal(records[i].cpu().numpy().reshape(B, 6), ref)
+        s.close()
+    finally:
+        dist.destroy_process_group()

@@ -14,14 +14,17 @@ for N in [int(v) for v in os.environ.get("STRESS_N", "40,30,63,100").split(",")]
     for start in [int(v) for v in os.environ.get("STRESS_SEEDS", "10000000,20000000").split(",")]:
         x0, p = sc.config2(B, start=start) if N != 100 else sc.config4(B // 4, start=start)
         Bn = x0.shape[0]
-        ocfg = orc.config_like(capi.default_config(N, 0.35))
-        xo, uo, so, io = orc.rti_batch(ocfg, x0, p)
         x1 = x0 + 0.02 * np.roll(x0, 1, axis=0) * 0 + 0.01 * (np.roll(x0, 1, axis=0) - x0)
         p1 = p + 0.01 * (np.roll(p, 1, axis=0) - p)
-        xo2, uo2, so2, io2 = orc.rti_batch(ocfg, x1, p1, xo.copy(), uo.copy(), cold=False)
-        for kern in ("wave", "quad") if N <= 63 else ("wave",):
+        kerns = [k for k in os.environ.get("STRESS_KERNELS", "wave,quad").split(",") if k == "wave" or N <= 63]
+        for kern in kerns:
+            # the four-slot kernel has no active-set polish: both sides run the interior point to its own test
+            over = dict(polish=0) if kern == "quad" else {}
+            ocfg = orc.config_like(capi.default_config(N, 0.35, **over))
+            xo, uo, so, io = orc.rti_batch(ocfg, x0, p)
+            xo2, uo2, so2, io2 = orc.rti_batch(ocfg, x1, p1, xo.copy(), uo.copy(), cold=False)
             os.environ["NMPC_KERNEL"] = kern
-            s = capi.BatchSolver(N=N, dt=0.35, capacity=Bn)
+            s = capi.BatchSolver(N=N, dt=0.35, capacity=Bn, **over)
             s.set_x0(x0); s.set_params(p)
             s.solve(Bn); g = s.get(Bn)
             s.set_iterate(xo, uo); s.set_x0(x1); s.set_params(p1)

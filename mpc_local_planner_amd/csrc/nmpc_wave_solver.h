@@ -482,7 +482,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
             const double cst = 0.5 * (Q11 * cte * cte + Q22 * epsi * epsi + Q33 * ev * ev +
                                       Q44 * xb[4] * xb[4] + Q55 * xb[5] * xb[5] +
                                       R00 * ub_[0] * ub_[0] + R11 * ub_[1] * ub_[1]);
-            cost_out = w.sum(act ? cst : 0.0);
+            cost_out = w.uniform(w.sum(act ? cst : 0.0));
             if (W::kSqp) {
                 // NLP KKT residuals at this iterate with the last QP's multipliers: acados' SQP
                 // termination test (stationarity, equality, inequality, complementarity, each in the
@@ -566,7 +566,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 c_loc = fmax(c_loc, fmax(fmin(tl[q], ll[q]), fmin(tu[q], lu[q])));
             }
             // (a divide is an eleven-instruction dependent sequence on gfx950: reciprocal and multiply instead)
-            mu = w.sum(mu_loc) * inv_mcount;
+            mu = w.uniform(w.sum(mu_loc) * inv_mcount);
             // the pairwise test only decides once the averages have converged (uniform over the instance)
             const bool near_end = it > 0 && mu <= pb.tol_mu && lin_scale <= pb.tol_lin;
             const double cmax = near_end ? w.max(c_loc) : 1.0;
@@ -1098,18 +1098,18 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                         r_loc = fmax(r_loc, fmax(-dtl[q] * itl[q], -dtu[q] * itu[q]));
                         r_loc = fmax(r_loc, mq[q] ? fmax(1.0 + dtl[q] * itl[q], 1.0 + dtu[q] * itu[q]) : 0.0);
                     }
-                    const double a_aff = w.rcp(fmax(1.0, w.max(r_loc)));
+                    const double a_aff = w.uniform(w.rcp(fmax(1.0, w.max(r_loc))));
                     double ma = 0.0;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         ma += (tl[q] + a_aff * dtl[q]) * (ll[q] + a_aff * dll[q]) +
                               (tu[q] + a_aff * dtu[q]) * (lu[q] + a_aff * dlu[q]);
-                    mu_aff = w.sum(ma) * inv_mcount;
+                    mu_aff = w.uniform(w.sum(ma) * inv_mcount);
                     const double sr = mu_aff * w.rcp(mu);
-                    smu = sr * sr * sr * mu;
+                    smu = w.uniform(sr * sr * sr * mu);
                     // Mehrotra's second-order term, damped when the affine step is almost fully
                     // blocked (undamped it over-corrects and the iteration can cycle)
-                    csc = fmin(1.0, 4.0 * a_aff);
+                    csc = w.uniform(fmin(1.0, 4.0 * a_aff));
                     // (the pick-up reads above are ordered before these stores by the reductions)
                     if (act) {
                         double *sl = stg + tid * ST + O_D;
@@ -1157,7 +1157,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     }
                     const double a_max = w.rcp(w.max(r_loc));
                     const double tau = fmax(pb.tau, 1.0 - mu_aff);
-                    const double alpha = fmin(1.0, tau * a_max);
+                    const double alpha = w.uniform(fmin(1.0, tau * a_max));
 #pragma unroll
                     for (int m = 0; m < 8; ++m) z[m] += alpha * (dzs[m] + dzl[m]);
 #pragma unroll
@@ -1167,7 +1167,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     }
 #pragma unroll
                     for (int m = 0; m < 6; ++m) rb[m] *= (1.0 - alpha);
-                    lin_scale *= (1.0 - alpha);
+                    lin_scale = w.uniform(lin_scale * (1.0 - alpha));
                     ++it;
                 }
             }

@@ -133,7 +133,8 @@ int nmpc_set_bounds(nmpc_handle *h, const double *bnd, int B);
  * handle's horizon, which sizes the buffers); dt is the handle's.  NULL: every instance uses cfg.N again.
  * The reference fixes N at code generation (config/mpc_params.yaml:35, acados/mpcPathTracking.py:9), the
  * counterpart is one generated solver per N.  An instance with horizon n uses nodes 0..n of its iterate
- * and of nmpc_get's x / u rows (later nodes are left as they are); its result is bit-identical to that of
+ * and of nmpc_get's x / u rows (later nodes are left as they are, except that input row n carries the
+ * solver's warm-start hint, not an input); its result is bit-identical to that of
  * a handle created with cfg.N = n.  Changing an instance's horizon makes its old iterate meaningless:
  * reset it (nmpc_reset).  Solved by the one-instance-per-workgroup kernel. */
 int nmpc_set_horizons(nmpc_handle *h, const int32_t *N, int B);

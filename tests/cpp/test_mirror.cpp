@@ -2,6 +2,7 @@
 // time with mpc::Acados::PathTracking::solve (three calls: cold + 2 warm, like the reference's
 // static solver) and as one batch with solveBatch, and prints the trajectories for the Python
 // test to compare with the oracle.  Needs a GPU.
+#include <chrono>
 #include <cstdio>
 #include <fstream>
 #include <vector>
@@ -107,6 +108,27 @@ int main(int argc, char **argv) {
             printf(" %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g", o.x.x, o.x.y, o.x.psi, o.x.vel, o.x.delta,
                    o.x.throttle, o.u.deltaDot, o.u.throttleDot);
         printf("\n");
+    }
+    // solveBatch at the headline size (4096 vehicles): host time of one call, MPCReturn packing included
+    // (the trajectories come through nmpc_get_view: split on the device, read in place from pinned memory)
+    {
+        const int BB = 4096;
+        std::vector<mpc::State> st;
+        std::vector<mpc::Acados::PathTrackingParams> pr;
+        for (int b = 0; b < BB; ++b) { st.push_back(states[b % B]); pr.push_back(params[b % B]); }
+        mpc::Acados::PathTracking big{states[0], N, 0.35, BB};
+        double best = 1e30;
+        size_t n_ok = 0;
+        for (int call = 0; call < 4; ++call) {
+            nmpc_reset(big.handle(), nullptr, BB);
+            const auto t0 = std::chrono::steady_clock::now();
+            auto r = big.solveBatch(st, pr);
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (call > 0 && ms < best) best = ms;
+            n_ok = 0;
+            for (auto &e : r) n_ok += e.success && e.mpcHorizon.size() == (size_t)N;
+        }
+        printf("batchtime %d %zu %.4f\n", BB, n_ok, best);
     }
     // error behaviour: an impossible horizon throws from the constructor (AcadosPathTracking.cpp:42-47)
     try {

@@ -92,6 +92,8 @@ class Hip:
         self.l.hipEventSynchronize.argtypes = [C.c_void_p]
         self.l.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
         self.l.hipEventDestroy.argtypes = [C.c_void_p]
+        self.l.hipMemcpy2DAsync.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
+                                            C.c_int, C.c_void_p]
 
     def event(self):
         e = C.c_void_p()
@@ -100,6 +102,10 @@ class Hip:
 
     def record(self, e, stream):
         assert self.l.hipEventRecord(e, stream) == 0
+
+    def copy_rows(self, dst, dpitch, src, spitch, width, rows, stream):
+        """Device-to-device copy of `rows` rows of `width` bytes (hipMemcpyDeviceToDevice = 3) on `stream`."""
+        assert self.l.hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, 3, stream) == 0
 
     def elapsed_ms(self, a, b):
         assert self.l.hipEventSynchronize(b) == 0
@@ -395,6 +401,40 @@ def main():
     dt_warm, kms_warm = timed(solver, args.steps, False, False, warm_sets, with_events=True)
     gw = solver.get(B)
     n_ipm_warm = float(gw["ipm_iters"].mean())
+    # receding sequence: the measurement of tick t + 1 is the model's own prediction x_1 of tick t (copied on
+    # the device, on the solver's stream), the path parameters stay, the iterate is kept without a shift --
+    # the reference's operating mode (src/PathTrackingSys.cpp:58-61) with a perfect plant and a path that is
+    # fixed in the vehicle frame.  Inputs move as far as a vehicle moves in dt, not by a share of the scenario spread.
+    x_rec = cold_sets[0][0].clone()
+    p_rec = cold_sets[0][1]
+    traj_ptr = solver.device_ptr(1)
+
+    def receding(steps, events=None):
+        for s in range(steps):
+            if events is not None:
+                hip.record(events[2 * s], solver.stream())
+            solver.solve(B)
+            hip.copy_rows(C.c_void_p(x_rec.data_ptr()), 48, C.c_void_p(traj_ptr + 64), (N + 1) * 64, 48, B, solver.stream())
+            if events is not None:
+                hip.record(events[2 * s + 1], solver.stream())
+
+    solver.set_inputs_device(C.c_void_p(x_rec.data_ptr()), C.c_void_p(p_rec.data_ptr()), B)
+    solver.reset(None, B)
+    receding(5)
+    ev_rec = [hip.event() for _ in range(2 * args.steps)]
+    barrier(solver)
+    t0 = time.perf_counter()
+    receding(args.steps, ev_rec)
+    barrier(solver)
+    dt_rec = time.perf_counter() - t0
+    kms_rec = [hip.elapsed_ms(ev_rec[2 * s], ev_rec[2 * s + 1]) for s in range(args.steps)]
+    gr = solver.get(B)
+    rec = {"value": B * args.steps / dt_rec, "ms_per_step": 1e3 * dt_rec / args.steps,
+           "step_ms_median": float(np.median(kms_rec)), "mean_ipm_iters": float(gr["ipm_iters"].mean()),
+           "ok_frac": float((gr["status"] == 0).mean()), "ticks": 5 + args.steps,
+           "note": "per rank; warm-started RTI calls of a receding sequence: x0 of the next tick = x_1 of this tick's "
+                   "solution (device copy on the solver's stream, inside the timed region), parameters fixed, "
+                   "iterate kept without shift"}
     dt_nogather = None
     if dist_on:
         run(solver, 2, True, False, cold_sets)
@@ -451,6 +491,7 @@ def main():
                    "kernel_ms": float(np.mean(kms_warm)), "kernel_ms_median": float(np.median(kms_warm)),
                    "mean_ipm_iters": n_ipm_warm,
                    "note": "warm-started RTI calls; inputs move by 3 % of the spread between calls"}
+    out["warm_receding"] = rec
     if dt_nogather:
         out["multi_gpu"] = {"with_gather": value, "without_gather": total_solves / dt_nogather,
                             "dist_world_size": dist.get_world_size(), "backend": dist.get_backend(),

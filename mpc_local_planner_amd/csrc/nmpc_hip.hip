@@ -369,7 +369,50 @@ __global__ void __launch_bounds__(64 * NW, 2) nmpc_solve_kernel(KernelArgs a)
 // element-wise work of one instance each; wave 0 also sweeps all four (one per 16-lane DPP row).
 // Shares the vector-sweep stages, reductions and reciprocal with the one-wave policy.
 constexpr int QUAD_THREADS = 64 * nmpcq::QI;
+#ifdef NMPC_QUAD_TIMELINE
+// Debug build (tools/quad_timeline.py): shader-clock ticks per phase of the interior-point iteration, summed
+// over the launch per wave index: g_quad_tl[wave][segment], segment = time since the previous stamp.
+__device__ unsigned long long g_quad_tl[4][16];
+#endif
 struct GpuQuad : GpuWave<1, false> {
+#ifdef NMPC_QUAD_TIMELINE
+    // accumulators of this wave in LDS (16 per wave, behind the workgroup's flags); flushed to the global
+    // table once, when the workgroup ends -- per-stamp global atomics from 2048 waves on 64 addresses
+    // saturate one L2 channel and slowed the launch by 1.7x
+    // (state in scalar registers / LDS only: two more vector registers live through the sweeps made the
+    // register-resident factor stage spill)
+    int tl_off = 0;          // offset of this wave's accumulators in LDS, in 8-byte words (uniform)
+    __device__ __forceinline__ unsigned long long *tl_ptr() { return (unsigned long long *)lds_ + __builtin_amdgcn_readfirstlane(tl_off); }
+    __device__ __forceinline__ void stamp_init(double *area)
+    {
+        tl_off = __builtin_amdgcn_readfirstlane((int)(area - lds_) + 16 * wave());
+        unsigned long long *tl = tl_ptr();
+        if ((threadIdx.x & 63) < 15) tl[threadIdx.x & 63] = 0ull;
+        if ((threadIdx.x & 63) == 15) tl[15] = (unsigned long long)__builtin_readcyclecounter();    // previous stamp
+    }
+    __device__ __forceinline__ void stamp(int id)
+    {
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long *tl = tl_ptr();
+            const unsigned long long t = (unsigned long long)__builtin_readcyclecounter();
+            tl[id] += t - tl[15];
+            tl[15] = (unsigned long long)__builtin_readcyclecounter();
+        }
+    }
+    __device__ __forceinline__ void tick(int id)
+    {
+        if ((threadIdx.x & 63) == 0) tl_ptr()[id] += 1ull;
+    }
+    __device__ __forceinline__ void stamp_flush()
+    {
+        if ((threadIdx.x & 63) < 15) atomicAdd(&g_quad_tl[wave()][threadIdx.x & 63], tl_ptr()[threadIdx.x & 63]);
+    }
+#else
+    __device__ __forceinline__ void stamp(int) {}
+    __device__ __forceinline__ void tick(int) {}
+    __device__ __forceinline__ void stamp_init(double *) {}
+    __device__ __forceinline__ void stamp_flush() {}
+#endif
     __device__ __forceinline__ int wave() const { return (int)threadIdx.x >> 6; }
     __device__ __forceinline__ bool sweeper() const { return ((int)threadIdx.x >> 6) == 0; }   // slot 0's wave also sweeps
     // all four waves (the hardware barrier counts arriving waves, whichever branch they are in)
@@ -1173,6 +1216,18 @@ int nmpc_solve(nmpc_handle *h, int B, int mode, int max_iter, double tol)
     if (B > h->hist_B) h->hist_B = B;
     return launch_solve(a, mode, h->stream, hist, h->d_order, h->per_instance_N ? KERNEL_WAVE : h->kernel);
 }
+
+#ifdef NMPC_QUAD_TIMELINE
+extern "C" int nmpc_debug_quad_timeline(unsigned long long *out, int clear)
+{
+    if (out) HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_quad_tl), sizeof(unsigned long long) * 64));
+    if (clear) {
+        unsigned long long zero[64] = {};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_quad_tl), zero, sizeof(zero)));
+    }
+    return NMPC_OK;
+}
+#endif
 
 int nmpc_solve_static(const nmpc_config *cfg, int device, void *stream, int B, int cold, const double *d_x0,
                       const double *d_p, const double *d_W, const double *d_bnd, double *d_traj, double *d_ctrl,

@@ -60,7 +60,12 @@ constexpr int inst_stride(int N)
     return n + ((16 - n % 32) + 32) % 32;
 }
 constexpr int WG_FLAGS = 8;      // workgroup area after the four regions: done flags
-constexpr int quad_lds_doubles(int N) { return QI * inst_stride(N) + WG_FLAGS; }
+#ifdef NMPC_QUAD_TIMELINE
+constexpr int WG_TIMELINE = 64;   // debug build: per-wave phase accumulators behind the flags
+#else
+constexpr int WG_TIMELINE = 0;
+#endif
+constexpr int quad_lds_doubles(int N) { return QI * inst_stride(N) + WG_FLAGS + WG_TIMELINE; }
 
 // start values of the eight accumulators Ht_i of a factor stage: offset (doubles, in the stage) of the
 // entry lane j loads for row i.  Cost entries on and next to the diagonal, the gradient in the
@@ -149,6 +154,10 @@ NMPC_DEV void solve_quad(W &w, const Problem &pb, const Batch &bt)
     // addresses derived from it are set up per pass (opaque lane index), not held through the slot loop
     const int j16 = lane & 15;
 
+    // (w.stamp: phase timeline of the debug build NMPC_QUAD_TIMELINE, a no-op otherwise; segment = time since
+    // the previous stamp: 0 slot work + E-A, 1 barrier 1, 2 factor sweep, 3 forward sweep, 4 barrier 2,
+    // 5 E-B, 6 barrier 3, 7 backward sweep, 8 forward sweep, 9 barrier 4, 10 E-C, 11 one tick per iteration)
+    w.stamp_init(w.lds() + QI * IS + WG_FLAGS);
     for (;;) {
         double mu = 0.0;
         // ---- the slot: finish an instance that has terminated, fetch the next one
@@ -383,10 +392,13 @@ NMPC_DEV void solve_quad(W &w, const Problem &pb, const Batch &bt)
             }
         }
         if (lane == 0) flags[wv] = done ? 1.0 : 0.0;
+        w.stamp(0);
         w.sync();                                                         // barrier 1
+        w.stamp(1);
         // the queue is empty and no slot holds work: the workgroup ends (uniform over all four waves)
         const bool all_done = w.uniform_flag(flags[0] != 0.0 && flags[1] != 0.0 && flags[2] != 0.0 && flags[3] != 0.0);
-        if (all_done) break;
+        if (all_done) { w.stamp_flush(); break; }
+        w.tick(11);
 
         double dzs[8];
         double smu = 0.0, csc = 0.0, mu_aff = 0.0;
@@ -463,6 +475,7 @@ NMPC_DEV void solve_quad(W &w, const Problem &pb, const Batch &bt)
                     }
                     w.sweep_drain();
                     w.wsync();
+                    w.stamp(2);
                 } else {
                     // ---- backward vector sweep of the corrector, four instances
                     const int vl = w.opaque(j16) & 7;
@@ -494,6 +507,7 @@ NMPC_DEV void solve_quad(W &w, const Problem &pb, const Batch &bt)
                     }
                     w.sweep_drain();
                     w.wsync();
+                    w.stamp(7);
                 }
                 {
                     // ---- forward sweep, four instances (lanes 0..5 of a row: rows of dx_{k+1}, lanes 6,7: du_k)
@@ -537,8 +551,10 @@ NMPC_DEV void solve_quad(W &w, const Problem &pb, const Batch &bt)
                     }
                 }
                 w.sweep_priority(false);
+                w.stamp(pass == 0 ? 3 : 8);
             }
             w.sync();                                                     // barriers 2 and 4
+            w.stamp(pass == 0 ? 4 : 9);
             if (!done) {
                 // ---- stage layout: pick up the direction of this node (slot node-1 holds z_node)
                 double dzl[8];
@@ -628,7 +644,8 @@ NMPC_DEV void solve_quad(W &w, const Problem &pb, const Batch &bt)
                     ++it;
                 }
             }
-            if (pass == 0) w.sync();                                      // barrier 3 (corrector rhs visible)
+            w.stamp(pass == 0 ? 5 : 10);
+            if (pass == 0) { w.sync(); w.stamp(6); }                      // barrier 3 (corrector rhs visible)
         }
     }
 }

@@ -274,6 +274,10 @@ struct EmuQuad : EmuWave<false> {
     bool sweeper() const { return wave() == 0; }             // slot 0's wave also sweeps
     void sync() { barrier(g_s->wg, g_s->nt, tid_); }
     bool uniform_flag(bool b) { return b; }
+    void stamp(int) {}                                        // (timeline build of the GPU policy only)
+    void tick(int) {}
+    void stamp_init(double *) {}
+    void stamp_flush() {}
     int next_ticket(int *queue)                // one draw per wave, the same value on every lane
     {
         if (lane() == 0) g_s->itmp[wave()] = (*queue)++;

@@ -15,6 +15,7 @@ L = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(orc.__file__)), "libnmpc
 dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
 L.orc_rti_batch_mt_h.argtypes = [C.POINTER(orc.Config), C.c_int, dp, dp, dp, dp, dp, ip, ip, C.c_int, C.c_int]
 T = int(os.environ.get("THREADS", "8"))
+STALL_ITER = int(os.environ.get("STALL_ITER", "20"))     # the rule under study fires at this iteration (default: the shipped 20)
 
 
 def seq(cfg, x0, p, x1, p1, calls):
@@ -41,11 +42,11 @@ def study(name, N, gen, B, calls, **over):
     x0, p = gen(B)
     x1, p1 = gen(B, start=B)
     res = {}
-    for stall in (20, 0):
+    for stall in (STALL_ITER, 0):
         cfg = orc.default_config(N, 0.35, ipm_stall_iter=stall, **over)
         res[stall] = seq(cfg, x0, p, x1, p1, calls)
     lost = total = failed_off = 0
-    for (s_on, _), (s_off, _) in zip(res[20], res[0]):
+    for (s_on, _), (s_off, _) in zip(res[STALL_ITER], res[0]):
         lost += int(((s_on == 4) & (s_off == 0)).sum())
         failed_off += int((s_off != 0).sum())
         total += len(s_on)

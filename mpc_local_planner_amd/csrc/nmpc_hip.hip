@@ -27,6 +27,9 @@ namespace {
 // NW = waves per OCP instance (= per workgroup): 1 for N <= 63, 2 for N <= 127.  The sweeps always
 // run on the first wave; the other wave only takes part in the stage-layout work.
 // SQP = full SQP mode (the RTI instantiation carries none of the KKT-residual / costate code).
+#ifdef NMPC_WAVE_TIMELINE
+__device__ unsigned long long g_wave_tl[24];
+#endif
 template <int NW, bool SQP, bool COMPACT = false>
 struct GpuWave {
     using Layout = typename std::conditional<COMPACT, nmpcw::Layout48, nmpcw::Layout54>::type;
@@ -38,6 +41,35 @@ struct GpuWave {
     __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
     __device__ __forceinline__ int lane() const { return (int)threadIdx.x & 63; }
     __device__ __forceinline__ bool sweep_wave() const { return NW == 1 || threadIdx.x < 64; }
+#ifdef NMPC_WAVE_TIMELINE
+    // Debug build (tools/wave_timeline.py): shader-clock ticks of the sweeping wave per phase, accumulated in
+    // the last 24 slots of the instance's exchange area by thread 0 and added to g_wave_tl when the instance ends.
+    // State in a scalar register and LDS only (the kernel has no vector register to spare).
+    int tl_off = 0;
+    __device__ __forceinline__ unsigned long long *tl_ptr() { return (unsigned long long *)lds_ + __builtin_amdgcn_readfirstlane(tl_off); }
+    __device__ __forceinline__ void stamp_init(double *area)
+    {
+        tl_off = __builtin_amdgcn_readfirstlane((int)(area - lds_));
+        if (threadIdx.x < 23) tl_ptr()[threadIdx.x] = 0ull;
+        if (threadIdx.x == 23) tl_ptr()[23] = (unsigned long long)__builtin_readcyclecounter();    // previous stamp
+    }
+    __device__ __forceinline__ void stamp(int id)
+    {
+        if (threadIdx.x == 0) {
+            unsigned long long *tl = tl_ptr();
+            const unsigned long long t = (unsigned long long)__builtin_readcyclecounter();
+            tl[id] += t - tl[23];
+            tl[23] = (unsigned long long)__builtin_readcyclecounter();
+        }
+    }
+    __device__ __forceinline__ void tick(int id) { if (threadIdx.x == 0) tl_ptr()[id] += 1ull; }
+    __device__ __forceinline__ void stamp_flush();
+#else
+    __device__ __forceinline__ void stamp(int) {}
+    __device__ __forceinline__ void tick(int) {}
+    __device__ __forceinline__ void stamp_init(double *) {}
+    __device__ __forceinline__ void stamp_flush() {}
+#endif
     __device__ __forceinline__ double *lds() { return lds_; }
     // value the optimiser must treat as unknown: keeps per-sweep address set-up inside the
     // interior-point loop instead of hoisted into ~45 live registers
@@ -1216,6 +1248,24 @@ int nmpc_solve(nmpc_handle *h, int B, int mode, int max_iter, double tol)
     if (B > h->hist_B) h->hist_B = B;
     return launch_solve(a, mode, h->stream, hist, h->d_order, h->per_instance_N ? KERNEL_WAVE : h->kernel);
 }
+
+#ifdef NMPC_WAVE_TIMELINE
+template <int NW, bool SQP, bool COMPACT>
+__device__ __forceinline__ void GpuWave<NW, SQP, COMPACT>::stamp_flush()
+{
+    __syncthreads();
+    if (threadIdx.x < 23) atomicAdd(&g_wave_tl[threadIdx.x], tl_ptr()[threadIdx.x]);
+}
+extern "C" int nmpc_debug_wave_timeline(unsigned long long *out, int clear)
+{
+    if (out) HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_tl), sizeof(unsigned long long) * 24));
+    if (clear) {
+        unsigned long long zero[24] = {};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_wave_tl), zero, sizeof(zero)));
+    }
+    return NMPC_OK;
+}
+#endif
 
 #ifdef NMPC_QUAD_TIMELINE
 extern "C" int nmpc_debug_quad_timeline(unsigned long long *out, int clear)

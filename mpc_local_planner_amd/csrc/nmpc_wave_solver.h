@@ -151,7 +151,12 @@ constexpr int X_FT = 154;       // 1,0,0,0,1,0: forward-sweep coefficients of dx
 constexpr int X_UNITB = 161;    // (1,0,0),-,(0,1,0): the unit columns again at ODD addresses for the backward sweep's
                                 // 8-byte loads: the stage lanes read even, odd, even addresses there, the unit lanes
                                 // odd, even, odd -- different banks at every stage alignment
+#ifdef NMPC_WAVE_TIMELINE
+constexpr int X_TL = 168;       // debug build (tools/wave_timeline.py): 24 per-phase clock accumulators of the sweeping wave
+constexpr int X_SIZE = 168 + 24;
+#else
 constexpr int X_SIZE = 168;
+#endif
 // horizons beyond 63 use two waves per instance (lane = node needs 128 threads); their cross-wave
 // reductions go through a small extra area owned by the wave policy
 constexpr int X_POLICY = 8;
@@ -296,6 +301,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
     double *const ct = w.lds();                 // pseudo-stage -1 (constant tables, z_0)
     double *const stg = ct + ST;                // stage k at stg + k*ST
     double *const xa = ct + (N + 1) * ST;       // exchange area
+    w.stamp_init(xa + X_SIZE - 24);            // (debug build NMPC_WAVE_TIMELINE: its accumulators are the area's last 24 slots)
 
     // ---------------------------------------------------------------- iterate (stage layout)
     const bool has_node = tid <= N;        // threads 0..N hold x_k
@@ -554,6 +560,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
             tries_left = pb.warm_tries;
         }
         w.sync();   // BA columns and constant tables visible
+        w.stamp(0);      // (phase timeline of the debug build NMPC_WAVE_TIMELINE; no-ops otherwise)
         for (;;) {
             double mu = 0.0;
             if (!pol) {
@@ -667,6 +674,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
             // terminal cost-to-go: none (no *_e cost or bound in mpcPathTracking.py)
             if (tid < 48) xa[X_P + tid] = 0.0;
             w.sync();
+            w.stamp(pol ? 8 : 1);
 
             // ---- factor sweep, k = N-1 .. 0 (augmented Riccati recursion), first wave only
             w.sweep_priority(true);
@@ -866,6 +874,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     }
                 }
             }
+            w.stamp(pol ? 9 : 2);
 
             // ---- pass 0: forward sweep with the affine right-hand side, then the corrector
             //      pass 1: backward + forward sweep of the corrector increment (homogeneous dynamics)
@@ -938,6 +947,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     }
                     w.sweep_drain();
                     w.wsync();
+                    w.stamp(pol ? 12 : 5);
                 }
                 // forward sweep.  Lanes 0..5 of every 16-lane row own a row of dx_{k+1}, lanes 6,7 own
                 // du_k[0], du_k[1] (lanes 8..15 repeat 0..7); dx_k sits in lanes 0..5 and reaches the
@@ -991,6 +1001,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                 }
                 w.sweep_priority(false);
                 w.sync();
+                if (!(pol && pass == 1)) w.stamp(pol ? (pass == 0 ? 10 : 14) : (pass == 0 ? 3 : 6));
                 // ---- stage layout: pick up the direction of this node (slot node-1 holds z_node)
                 double dzl[8];
                 {
@@ -1046,6 +1057,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                             if (mq[q] && s == 2 && !(smq[q] >= -tol_d)) { bad = 1; wsn &= ~(3 << (2 * q)); }
                         }
                         ++n_pol;
+                        w.tick(18);
                         // (the reduction also orders every node's reads of its neighbour's slots before the stores below)
                         if (w.max(bad ? 1.0 : 0.0) == 0.0) {
                             // the vertex: pinned quantities sit on their bounds to round-off, complementarity is
@@ -1071,6 +1083,7 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                         } else {
                             if (tries_left > 0) { --tries_left; wsp = wsn; }
                             else pol = 0;        // the interior-point iteration goes on from where it was
+                            w.stamp(13);
                             break;               // (no refinement of a rejected solve)
                         }
                     } else {
@@ -1169,7 +1182,9 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     for (int m = 0; m < 6; ++m) rb[m] *= (1.0 - alpha);
                     lin_scale = w.uniform(lin_scale * (1.0 - alpha));
                     ++it;
+                    w.tick(17);
                 }
+                w.stamp(pol ? (pass == 0 ? 11 : pass == 1 ? 13 : 15) : (pass == 0 ? 4 : 7));
             }
             if (polished) { qp_status = 0; break; }
         }
@@ -1261,6 +1276,9 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
         *io.sqp_iters = sqp_it;
         *io.cost = cost_out;
     }
+    w.stamp(16);
+    w.tick(19);
+    w.stamp_flush();
 }
 
 #undef NMPC_ZQ

@@ -94,6 +94,10 @@ struct EmuWave {
     double *lds() { return g_s->lds; }
     int opaque(int v) { return v; }
     double rounded(double v) { return v; }
+    void stamp(int) {}              // (phase timeline: debug builds of the GPU policy only)
+    void tick(int) {}
+    void stamp_init(double *) {}
+    void stamp_flush() {}
     void sched_fence() {}
     void fwd_fetch(const double *p1, const double *p3, const double *p2, double (&d)[9])
     {
@@ -274,10 +278,6 @@ struct EmuQuad : EmuWave<false> {
     bool sweeper() const { return wave() == 0; }             // slot 0's wave also sweeps
     void sync() { barrier(g_s->wg, g_s->nt, tid_); }
     bool uniform_flag(bool b) { return b; }
-    void stamp(int) {}                                        // (timeline build of the GPU policy only)
-    void tick(int) {}
-    void stamp_init(double *) {}
-    void stamp_flush() {}
     int next_ticket(int *queue)                // one draw per wave, the same value on every lane
     {
         if (lane() == 0) g_s->itmp[wave()] = (*queue)++;

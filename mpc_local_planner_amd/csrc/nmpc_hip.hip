@@ -41,6 +41,7 @@ struct GpuWave {
     __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
     __device__ __forceinline__ int lane() const { return (int)threadIdx.x & 63; }
     __device__ __forceinline__ bool sweep_wave() const { return NW == 1 || threadIdx.x < 64; }
+    __device__ __forceinline__ bool uniform_flag(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }   // b is the same on every lane
 #ifdef NMPC_WAVE_TIMELINE
     // Debug build (tools/wave_timeline.py): shader-clock ticks of the sweeping wave per phase, accumulated in
     // the last 24 slots of the instance's exchange area by thread 0 and added to g_wave_tl when the instance ends.
@@ -449,7 +450,6 @@ struct GpuQuad : GpuWave<1, false> {
     __device__ __forceinline__ bool sweeper() const { return ((int)threadIdx.x >> 6) == 0; }   // slot 0's wave also sweeps
     // all four waves (the hardware barrier counts arriving waves, whichever branch they are in)
     __device__ __forceinline__ void sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-    __device__ __forceinline__ bool uniform_flag(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
     // next ticket of the launch-wide queue: one atomic add per wave, the same value on every lane
     __device__ __forceinline__ int next_ticket(int *queue)
     {

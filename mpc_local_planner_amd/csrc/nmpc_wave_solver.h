@@ -818,7 +818,9 @@ NMPC_DEV void solve_instance(W &w, const Problem &pb, const InstanceIO &io)
                     w.sched_fence();
                     double Hvp = Hv, hjx = hj.x, hjy = hj.y, hix = hi.x, hiy = hi.y, h00 = H00, h01 = H01, h11 = H11;
                     double t0j = 0.0, t1j = 0.0;
-                    if (kPol) {
+                    // (a stage without pins -- most of them -- is the plain stage: the pins are the same on every
+                    // lane, so this is a branch of the whole wave, and skipping adds nothing but exact zeros)
+                    if (kPol && w.uniform_flag(pin0.x <= 0.5 || pin1.x <= 0.5)) {
                         // substitute the pinned inputs du_a = t_a . (dx, 1) into the stage's quadratic, then treat
                         // them as decoupled dummies (unit diagonal, zero row) in the elimination below
                         const bool f0 = pin0.x <= 0.5, f1 = pin1.x <= 0.5;

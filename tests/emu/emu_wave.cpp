@@ -91,6 +91,7 @@ struct EmuWave {
     int tid() const { return tid_; }
     int lane() const { return tid_ & (WAVE - 1); }
     bool sweep_wave() const { return tid_ < WAVE; }
+    bool uniform_flag(bool b) { return b; }
     double *lds() { return g_s->lds; }
     int opaque(int v) { return v; }
     double rounded(double v) { return v; }

@@ -102,7 +102,11 @@ int nmpc_create(const nmpc_config *cfg, int capacity, int device, nmpc_handle **
 /* Replaces path_tracking_acados_free + _free_capsule (src/AcadosPathTracking.cpp:51-64). */
 int nmpc_destroy(nmpc_handle *h);
 
-/* Replaces Solver::setInitCondition: lbx0 = ubx0 = x0 (src/AcadosSolver.cpp:15-26). */
+/* Replaces Solver::setInitCondition: lbx0 = ubx0 = x0 (src/AcadosSolver.cpp:15-26).
+ * nmpc_set_x0 / nmpc_set_params copy the caller's rows into pinned staging memory of the handle and enqueue the
+ * transfer on the handle's stream: the caller's buffer may be reused as soon as the call returns, every later
+ * call on the handle sees the new values, and no call waits for the device (a consumer on ANOTHER stream
+ * must order itself behind nmpc_stream(h), or call nmpc_sync first). */
 int nmpc_set_x0(nmpc_handle *h, const double *x0, int B);
 
 /* Replaces PathTracking::setParams / path_tracking_acados_update_params for stages 0..N

@@ -640,6 +640,13 @@ struct nmpc_handle {
     // trajectories out (nmpc_get / nmpc_get_view): x and u split on the device, then one DMA each into pinned
     // host memory owned by the handle; allocated at the first call that asks for trajectories
     double *d_xs = nullptr, *d_us = nullptr, *h_px = nullptr, *h_pu = nullptr;
+    // inputs in (nmpc_set_x0 / nmpc_set_params): pinned staging rows [cap][6] each, so that the copy to the
+    // device is a true asynchronous DMA and the call returns after one host memcpy; the event says when the
+    // DMA that last read a staging buffer has finished (it must not be overwritten before).  Allocated at the
+    // first upload; without them (allocation refused) the upload is a synchronous copy from the caller's memory.
+    double *h_sx0 = nullptr, *h_sp = nullptr;
+    hipEvent_t ev_sx0 = nullptr, ev_sp = nullptr;
+    bool stage_tried = false;
     // path front-end / closed loop (allocated by nmpc_set_track)
     double *d_track = nullptr, *d_ws = nullptr, *d_pv = nullptr, *d_rot = nullptr, *d_xy = nullptr;
     double *d_wsfe = nullptr;     // the world states the last front-end pass transformed (the plant moves d_ws on)
@@ -1089,18 +1096,48 @@ int nmpc_destroy(nmpc_handle *h)
         if (p && !hip_ok(hipFree(p), "hipFree")) rc = NMPC_EHIP;
     for (void *p : {(void *)h->d_xs, (void *)h->d_us})
         if (p && !hip_ok(hipFree(p), "hipFree")) rc = NMPC_EHIP;
-    for (void *p : {(void *)h->h_px, (void *)h->h_pu})
+    for (void *p : {(void *)h->h_px, (void *)h->h_pu, (void *)h->h_sx0, (void *)h->h_sp})
         if (p && !hip_ok(hipHostFree(p), "hipHostFree")) rc = NMPC_EHIP;
+    for (hipEvent_t e : {h->ev_sx0, h->ev_sp})
+        if (e && !hip_ok(hipEventDestroy(e), "hipEventDestroy")) rc = NMPC_EHIP;
     if (!hip_ok(hipStreamDestroy(h->stream), "hipStreamDestroy")) rc = NMPC_EHIP;
     delete h;
     return rc;
 }
 
-static int upload(nmpc_handle *h, double *dst, const double *src, int B, int width)
+static int upload(nmpc_handle *h, double *dst, const double *src, int B, int width, double *nmpc_handle::*stage = nullptr,
+                  hipEvent_t nmpc_handle::*ev = nullptr)
 {
     if (!h || !src || B <= 0 || B > h->capacity) return NMPC_EINVAL;
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * (size_t)B * width, hipMemcpyHostToDevice, h->stream));
+    const size_t bytes = sizeof(double) * (size_t)B * width;
+    if (stage && !h->stage_tried) {
+        // once per handle, all or nothing (a refusal is not an error: the synchronous path below remains)
+        h->stage_tried = true;
+        const size_t cap_bytes = sizeof(double) * (size_t)h->capacity * 6;
+        double *a = nullptr, *b = nullptr;
+        hipEvent_t ea = nullptr, eb = nullptr;
+        if (hipHostMalloc((void **)&a, cap_bytes, hipHostMallocDefault) == hipSuccess &&
+            hipHostMalloc((void **)&b, cap_bytes, hipHostMallocDefault) == hipSuccess &&
+            hipEventCreateWithFlags(&ea, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&eb, hipEventDisableTiming) == hipSuccess) {
+            h->h_sx0 = a; h->h_sp = b; h->ev_sx0 = ea; h->ev_sp = eb;
+        } else {
+            (void)hipGetLastError();
+            if (a) (void)hipHostFree(a);
+            if (b) (void)hipHostFree(b);
+            if (ea) (void)hipEventDestroy(ea);
+            if (eb) (void)hipEventDestroy(eb);
+        }
+    }
+    if (stage && h->*stage) {
+        HIP_TRY(hipEventSynchronize(h->*ev));          // the previous DMA out of this staging buffer (long done, as a rule)
+        memcpy(h->*stage, src, bytes);                  // the caller's buffer may be reused as soon as we return
+        HIP_TRY(hipMemcpyAsync(dst, h->*stage, bytes, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipEventRecord(h->*ev, h->stream));
+        return NMPC_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
     // the caller's buffer may be reused as soon as we return
     HIP_TRY(hipStreamSynchronize(h->stream));
     return NMPC_OK;
@@ -1108,14 +1145,14 @@ static int upload(nmpc_handle *h, double *dst, const double *src, int B, int wid
 
 int nmpc_set_x0(nmpc_handle *h, const double *x0, int B)
 {
-    const int rc = upload(h, h ? h->d_x0 : nullptr, x0, B, 6);
+    const int rc = upload(h, h ? h->d_x0 : nullptr, x0, B, 6, &nmpc_handle::h_sx0, &nmpc_handle::ev_sx0);
     if (rc == NMPC_OK) h->in_x0 = h->d_x0;
     return rc;
 }
 
 int nmpc_set_params(nmpc_handle *h, const double *p, int B)
 {
-    const int rc = upload(h, h ? h->d_p : nullptr, p, B, 6);
+    const int rc = upload(h, h ? h->d_p : nullptr, p, B, 6, &nmpc_handle::h_sp, &nmpc_handle::ev_sp);
     if (rc == NMPC_OK) h->in_p = h->d_p;
     return rc;
 }
@@ -1387,6 +1424,10 @@ static int stage_trajectories(nmpc_handle *h, int B)
     hipLaunchKernelGGL(nmpc_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_traj, B, (int)N,
                        h->d_xs, h->d_us);
     HIP_TRY(hipGetLastError());
+    // The transfers are issued on an idle stream: enqueued behind a solve that is still running, the same two
+    // copies measured 1.5x slower end to end (2.9 M against 4.25 M trajectories/s at B = 4096) -- the runtime
+    // picks its copy path when the call is made.  The callers wait for the stream anyway.
+    HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpyAsync(h->h_px, h->d_xs, sizeof(double) * n * 6, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(h->h_pu, h->d_us, sizeof(double) * (size_t)B * N * 2, hipMemcpyDeviceToHost, h->stream));
     return NMPC_OK;

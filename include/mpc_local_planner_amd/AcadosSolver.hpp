@@ -199,11 +199,12 @@ class PathTracking : public Solver {
         std::vector<double> x0(static_cast<size_t>(B) * 6), p(static_cast<size_t>(B) * 6);
         for (int b = 0; b < B; ++b) {
             const auto s = states[static_cast<size_t>(b)].toArray();
-            const auto q = params[static_cast<size_t>(b)].toVec();
-            for (int i = 0; i < 6; ++i) {
-                x0[static_cast<size_t>(b) * 6 + i] = s[static_cast<size_t>(i)];
-                p[static_cast<size_t>(b) * 6 + i] = q[static_cast<size_t>(i)];
-            }
+            const PathTrackingParams &q = params[static_cast<size_t>(b)];     // (toVec() would allocate per vehicle)
+            double *pr = p.data() + static_cast<size_t>(b) * 6;
+            for (int i = 0; i < 6; ++i) x0[static_cast<size_t>(b) * 6 + i] = s[static_cast<size_t>(i)];
+            for (int i = 0; i < 4; ++i) pr[i] = q.polyCoeffs[static_cast<size_t>(i)];
+            pr[4] = q.pitch;
+            pr[5] = q.vRef;
         }
         check(nmpc_set_x0(handle_, x0.data(), B), "nmpc_set_x0");
         check(nmpc_set_params(handle_, p.data(), B), "nmpc_set_params");

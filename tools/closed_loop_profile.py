@@ -9,7 +9,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mpc_local_planner_amd import capi, scenarios as sc
 
-B, ticks = 65536, 20
+B, ticks = 65536, int(os.environ.get("TICKS", "20"))
 track = sc.test_track()
 ws, pv = sc.cars_on_track(B, track)
 s = capi.BatchSolver(N=40, dt=0.35, capacity=B)

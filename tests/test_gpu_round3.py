@@ -410,3 +410,45 @@ def test_gather_pipeline_cuda_sync_single_rank_finish_blocks_the_host():
         s.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_closed_loop_forty_ticks_free_running_against_the_oracle_loop():
+    """The reference's operating mode over many ticks (src/main.cpp:14-26, src/PathTrackingSys.cpp:58-61: iterate
+    kept without shift, one QP per tick), free-running on both sides, the oracle carrying its own warm-start
+    hints: with every QP finished on its vertex round-off is no longer amplified from tick to tick, so the
+    world states still agree after 40 ticks, and the last tick takes the same number of factorisations -- warm
+    attempts, corrections and cold paths included."""
+    from test_gpu_frontend_closed_loop import world_states as ws_gen
+    N, B, steps, dtp = 40, 32, 40, 1.0 / 30.0
+    t, ws, pv = ws_gen(B, seed=11)
+    s = capi.BatchSolver(N=N, dt=0.35, capacity=B)
+    s.set_track(t)
+    wend, trace, nfail = s.closed_loop(ws, pv, steps, dt_plant=dtp, trace=True, count_failures=True)
+    g = s.get(B)
+    s.close()
+    assert nfail == 0
+    pcfg, cfg = orc.default_config(N, dtp), _ocfg(N)
+    to = np.zeros((steps, B, 6))
+    its = np.zeros(B, dtype=int)
+    for i in range(B):
+        w = ws[i].copy()
+        xt = ut = None
+        hint = np.zeros(1)
+        for k in range(steps):
+            rot, c = orc.calc_coeffs(t, w)
+            xs = np.array([0.0, 0.0, rot, w[3], w[4], w[5]])
+            p = np.array([c[0], c[1], c[2], c[3], pv[i, 0], pv[i, 1]])
+            if xt is None:
+                xt, ut = orc.init_guess(cfg, xs)
+                hint[:] = 0
+            st = orc.rti(cfg, xs, p, xt, ut, hint=hint)
+            assert st.status == 0
+            its[i] = st.ipm_iters
+            x = w.copy(); x[4] = xt[1, 4]; x[5] = xt[1, 5]
+            phi, _, _ = orc.rk4_sens(pcfg, x, np.zeros(2), np.array([0, 0, 0, 0, pv[i, 0], 0.0]))
+            w[:4] = phi[:4]; w[4] = xt[1, 4]; w[5] = xt[1, 5]
+            to[k, i] = w
+    err = np.abs(trace - to).max(axis=2)                    # [steps, B]
+    assert err[0].max() <= 1e-12 and err.max() <= 1e-8, (err[0].max(), err.max())
+    assert np.median(err[-1]) <= 1e-12
+    assert (g["ipm_iters"] == its).mean() >= 0.9, (g["ipm_iters"], its)

@@ -1,3 +1,6 @@
+"""Free-running closed loop (front-end -> SQP-RTI -> plant, 40 ticks at 30 Hz) on the GPU against the oracle loop
+with its own warm-start hints: prints the world-state difference by tick and the factorisation counts of the
+last tick.  gpurun -- python tools/closed_loop_parity_probe.py"""
 import sys
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
